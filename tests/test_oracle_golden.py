@@ -203,7 +203,8 @@ def test_hot_path(golden, variant, training):
         close_l2(gr[0][:, ::16], g["gfL"], 2e-3, "gfL"); close_l2(gr[1][:, ::16], g["gfR"], 2e-3, "gfR")
         gn = ["g_dres0_w", "g_dres1_bn2_w", "g_cva2_deconv_w", "g_cva1_q00_w", "g_cls3_w", "g_cva3_fuse_bnb", "g_cls1_w"]
         for got, name in zip(gr[2:], gn):
-            close_l2(thin(got), g[name], 2e-3, name)
+            # a BN bias that feeds a batch-stat BN is almost exactly cancelled -> tiny, noisy gradient
+            close_l2(thin(got), g[name], 1e-2 if name.endswith("bnb") else 2e-3, name)
         close(sd["dres0.0.1.running_mean"], g["rm_dres0"], 1e-5)
     else:
         close(r["prob_volume2"].squeeze(1), g["prob_volume2"], 2e-5, "prob_volume2")
