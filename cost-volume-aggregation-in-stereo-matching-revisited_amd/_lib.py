@@ -1,0 +1,55 @@
+"""ctypes binding of include/dca_hip.h.  There is NO fallback: if libdca_hip.so is missing or does not
+export every symbol the header declares, importing the ops raises."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdca_hip.so")
+
+_p, _i, _l, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double
+
+# name -> (restype, argtypes); mirrors include/dca_hip.h one to one
+SIGNATURES = {
+    "dca_gwc_volume_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "dca_gwc_volume_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "dca_concat_volume_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "dca_concat_volume_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "dca_softargmin_fwd": (_i, [_p, _p, _i, _i, _l, _i, _p]),
+    "dca_softargmin_bwd": (_i, [_p, _p, _p, _i, _i, _l, _i, _p]),
+    "dca_conv3d_prep_weight": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "dca_conv3d_forward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _f] + [_i] * 14 + [_p]),
+    "dca_conv3d_wgrad_workspace": (_l, [_i] * 8),
+    "dca_conv3d_wgrad": (_i, [_p, _p, _p, _p] + [_i] * 11 + [_l, _l, _p]),
+    "dca_bn_num_chunks": (_i, [_i, _l]),
+    "dca_bn_stats": (_i, [_p, _p, _i, _i, _l, _p]),
+    "dca_bn_finalize": (_i, [_p, _i, _d, _p, _p, _p, _p, _f, _f, _i, _p, _i, _p]),
+    "dca_bn_apply": (_i, [_p, _p, _p, _p, _p, _i, _i, _l, _f, _p]),
+    "dca_bn_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _l, _f, _i, _p]),
+    "dca_avgpool3d_fwd": (_i, [_p, _p, _l, _i, _i, _i, _p]),
+    "dca_avgpool3d_bwd": (_i, [_p, _p, _l, _i, _i, _i, _p]),
+    "dca_trilinear_fwd": (_i, [_p, _p, _l, _i, _i, _i, _i, _p]),
+    "dca_trilinear_bwd": (_i, [_p, _p, _l, _i, _i, _i, _i, _p]),
+    "dca_context_inject_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _l, _p]),
+    "dca_context_inject_bwd": (_i, [_p] * 11 + [_i, _i, _i, _l, _p]),
+    "dca_disp_attention_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _l, _p]),
+    "dca_disp_attention_bwd": (_i, [_p] * 7 + [_i, _i, _i, _l, _p]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads the HIP library and binds every C-ABI symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the DCANet hot path has no CPU/PyTorch fallback. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950).")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing -> loud
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib

@@ -1,0 +1,336 @@
+// DCA module: homogeneous-region context injection and per-pixel disparity attention (gfx950).
+//
+// Replaces (reference):
+//  * SemanticLevelContext.forward, models/augment/semantic_level.py:96-126 -- the python loop over
+//    (batch, disparity class) with boolean-mask gathers and one host sync per class.  Closed form
+//    (SURVEY Appendix B.3): p = softmax_k(preds), k* = argmax_k p, w = softmax of p[k*] over the
+//    pixels that share (b, k*), key = x * (1 + [k == k*] * w).  Two launches, no host sync.
+//  * SelfAttentionBlock.forward core, models/augment/SelfAttention_bn.py:70-94 -- 4 heads of 8
+//    channels, sequence = the n = D/8 disparity bins of one pixel, softmax(q k^T / sqrt 8) v.
+//    The n x n score matrix never leaves registers (online softmax); K/V tiles of 32 pixels are
+//    staged in LDS with the pixel index on the lanes (coalesced along W, conflict free).
+#include "dca_common.h"
+#include "../../include/dca_hip.h"
+
+// ---------------------------------------------------------------------------------------------
+// context injection, forward
+// ---------------------------------------------------------------------------------------------
+// per pixel: k*, e = exp(p[k*] - 1), pm = p[k*]; denom[b][k] += e over pixels with k* = k
+__global__ __launch_bounds__(256) void ctx_stats_kernel(const float* __restrict__ preds, int* __restrict__ kstar,
+                                                        float* __restrict__ e_out, float* __restrict__ pm_out,
+                                                        float* __restrict__ denom, int n, long HW) {
+  extern __shared__ float cls[];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  for (int k = tid; k < n; k += 256) cls[k] = 0.f;
+  __syncthreads();
+  const long pix = (long)blockIdx.x * 256 + tid;
+  if (pix < HW) {
+    const float* lp = preds + (long)b * n * HW + pix;
+    float m = -INFINITY;
+    for (int k = 0; k < n; ++k) m = fmaxf(m, lp[k * HW]);
+    float s = 0.f;
+    for (int k = 0; k < n; ++k) s += expf(lp[k * HW] - m);
+    float best = -1.f;
+    int kb = 0;
+    for (int k = 0; k < n; ++k) {
+      const float p = expf(lp[k * HW] - m) / s;
+      if (p > best) { best = p; kb = k; }   // first maximum on ties (argmax)
+    }
+    const float e = expf(best - 1.0f);
+    kstar[(long)b * HW + pix] = kb;
+    e_out[(long)b * HW + pix] = e;
+    pm_out[(long)b * HW + pix] = best;
+    atomicAdd(&cls[kb], e);
+  }
+  __syncthreads();
+  for (int k = tid; k < n; k += 256)
+    if (cls[k] != 0.f) atomicAdd(&denom[b * n + k], cls[k]);
+}
+
+// out[b,c,k,pix] = in[b,c,k,pix] * (1 + [k == k*] e/denom[b,k*])   (forward: in = x; backward: in = dkey)
+__global__ void ctx_scale_kernel(const float* __restrict__ in, const int* __restrict__ kstar,
+                                 const float* __restrict__ e, const float* __restrict__ denom,
+                                 float* __restrict__ out, int C, int n, long HW, long total) {
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long pix = idx % HW;
+    long t = idx / HW;
+    const int k = t % n; t /= n;
+    const long b = t / C;
+    const int ks = kstar[b * HW + pix];
+    float sc = 1.f;
+    if (k == ks) sc += e[b * HW + pix] / denom[b * n + ks];
+    out[idx] = in[idx] * sc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// context injection, backward
+// ---------------------------------------------------------------------------------------------
+// dw[pix] = sum_c dkey[c,k*,pix] x[c,k*,pix];  T[b][k] += w*dw over the class
+__global__ __launch_bounds__(256) void ctx_bwd_reduce_kernel(const float* __restrict__ dkey,
+                                                             const float* __restrict__ x,
+                                                             const int* __restrict__ kstar,
+                                                             const float* __restrict__ e,
+                                                             const float* __restrict__ denom,
+                                                             float* __restrict__ dw, float* __restrict__ T, int C,
+                                                             int n, long HW) {
+  extern __shared__ float cls[];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  for (int k = tid; k < n; k += 256) cls[k] = 0.f;
+  __syncthreads();
+  const long pix = (long)blockIdx.x * 256 + tid;
+  if (pix < HW) {
+    const int ks = kstar[(long)b * HW + pix];
+    const long base = ((long)b * C * n + ks) * HW + pix;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += dkey[base + (long)c * n * HW] * x[base + (long)c * n * HW];
+    dw[(long)b * HW + pix] = s;
+    const float w = e[(long)b * HW + pix] / denom[b * n + ks];
+    atomicAdd(&cls[ks], w * s);
+  }
+  __syncthreads();
+  for (int k = tid; k < n; k += 256)
+    if (cls[k] != 0.f) atomicAdd(&T[b * n + k], cls[k]);
+}
+
+// dpreds[b,k,pix] = dm * pm * ([k==k*] - p_k),  dm = w (dw - T[b,k*])
+__global__ void ctx_bwd_preds_kernel(const float* __restrict__ preds, const int* __restrict__ kstar,
+                                     const float* __restrict__ e, const float* __restrict__ pm,
+                                     const float* __restrict__ denom, const float* __restrict__ dw,
+                                     const float* __restrict__ T, float* __restrict__ dpreds, int n, long HW,
+                                     long total) {
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long b = idx / HW, pix = idx % HW;
+    const int ks = kstar[idx];
+    const float w = e[idx] / denom[b * n + ks];
+    const float dm = w * (dw[idx] - T[b * n + ks]);
+    const float c0 = dm * pm[idx];
+    const float* lp = preds + b * n * HW + pix;
+    float* gp = dpreds + b * n * HW + pix;
+    float m = -INFINITY;
+    for (int k = 0; k < n; ++k) m = fmaxf(m, lp[k * HW]);
+    float s = 0.f;
+    for (int k = 0; k < n; ++k) s += expf(lp[k * HW] - m);
+    const float inv = 1.f / s;
+    for (int k = 0; k < n; ++k) {
+      const float p = expf(lp[k * HW] - m) * inv;
+      gp[k * HW] = c0 * ((k == ks ? 1.f : 0.f) - p);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// disparity attention, forward.  grid (ceil(HW/32), heads, B); thread = (pixel lane 0..31, query group 0..7)
+// ---------------------------------------------------------------------------------------------
+template <int QPT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                       const float* __restrict__ v, float* __restrict__ out, int C,
+                                                       int n, long HW) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* ks = smem;               // [8][n][32]
+  float* vs = smem + 8 * n * 32;  // [8][n][32]
+  const int tid = threadIdx.x, pl = tid & 31, qg = tid >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const long pix0 = (long)blockIdx.x * 32, pix = pix0 + pl;
+  const long hb = ((long)b * C + head * 8) * n * HW;  // offset of (b, head*8, 0, 0)
+  for (int it = tid; it < 8 * n * 32; it += 256) {
+    const int p = it & 31, cj = it >> 5;  // cj = c*n + j
+    const bool ok = pix0 + p < HW;
+    ks[it] = ok ? k[hb + (long)cj * HW + pix0 + p] : 0.f;
+    vs[it] = ok ? v[hb + (long)cj * HW + pix0 + p] : 0.f;
+  }
+  __syncthreads();
+  if (pix >= HW) return;
+  float qv[QPT][8], ctx[QPT][8], m[QPT], l[QPT];
+#pragma unroll
+  for (int t = 0; t < QPT; ++t) {
+    const int i = qg + 8 * t;
+    m[t] = -INFINITY;
+    l[t] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      qv[t][c] = (i < n) ? q[hb + ((long)c * n + i) * HW + pix] * 0.35355339059327373f : 0.f;
+      ctx[t][c] = 0.f;
+    }
+  }
+  for (int j = 0; j < n; ++j) {
+    float kj[8], vj[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      kj[c] = ks[(c * n + j) * 32 + pl];
+      vj[c] = vs[(c * n + j) * 32 + pl];
+    }
+#pragma unroll
+    for (int t = 0; t < QPT; ++t) {
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) s += qv[t][c] * kj[c];
+      const float mn = fmaxf(m[t], s);
+      const float corr = expf(m[t] - mn), p = expf(s - mn);
+      l[t] = l[t] * corr + p;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) ctx[t][c] = ctx[t][c] * corr + p * vj[c];
+      m[t] = mn;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < QPT; ++t) {
+    const int i = qg + 8 * t;
+    if (i >= n) continue;
+    const float inv = 1.f / l[t];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) out[hb + ((long)c * n + i) * HW + pix] = ctx[t][c] * inv;
+  }
+}
+
+// backward: dq (registers), dk/dv accumulated in LDS across the 8 query-group threads of a pixel.
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                       const float* __restrict__ v, const float* __restrict__ dout,
+                                                       float* __restrict__ dq, float* __restrict__ dk,
+                                                       float* __restrict__ dv, int C, int n, long HW) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tile = 8 * n * 32;
+  float* ks = smem;
+  float* vs = smem + tile;
+  float* dks = smem + 2 * tile;
+  float* dvs = smem + 3 * tile;
+  const int tid = threadIdx.x, pl = tid & 31, qg = tid >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const long pix0 = (long)blockIdx.x * 32, pix = pix0 + pl;
+  const long hb = ((long)b * C + head * 8) * n * HW;
+  const float scale = 0.35355339059327373f;
+  for (int it = tid; it < tile; it += 256) {
+    const int p = it & 31, cj = it >> 5;
+    const bool ok = pix0 + p < HW;
+    ks[it] = ok ? k[hb + (long)cj * HW + pix0 + p] : 0.f;
+    vs[it] = ok ? v[hb + (long)cj * HW + pix0 + p] : 0.f;
+    dks[it] = 0.f;
+    dvs[it] = 0.f;
+  }
+  __syncthreads();
+  if (pix < HW) {
+    for (int i = qg; i < n; i += 8) {
+      float qv[8], go[8], dqv[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        qv[c] = q[hb + ((long)c * n + i) * HW + pix] * scale;
+        go[c] = dout[hb + ((long)c * n + i) * HW + pix];
+        dqv[c] = 0.f;
+      }
+      // pass 1: softmax statistics and D = sum_j p_j dP_j (online)
+      float m = -INFINITY, l = 0.f, dnum = 0.f;
+      for (int j = 0; j < n; ++j) {
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          s += qv[c] * ks[(c * n + j) * 32 + pl];
+          dp += go[c] * vs[(c * n + j) * 32 + pl];
+        }
+        const float mn = fmaxf(m, s);
+        const float corr = expf(m - mn), p = expf(s - mn);
+        l = l * corr + p;
+        dnum = dnum * corr + p * dp;
+        m = mn;
+      }
+      const float inv = 1.f / l, Dsum = dnum * inv;
+      // pass 2: dS = p (dP - D); dq += dS k; dk += dS q; dv += p dout
+      for (int j = 0; j < n; ++j) {
+        float s = 0.f, dp = 0.f;
+        float kj[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          kj[c] = ks[(c * n + j) * 32 + pl];
+          s += qv[c] * kj[c];
+          dp += go[c] * vs[(c * n + j) * 32 + pl];
+        }
+        const float p = expf(s - m) * inv;
+        const float ds = p * (dp - Dsum);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          dqv[c] += ds * kj[c];
+          atomicAdd(&dks[(c * n + j) * 32 + pl], ds * qv[c]);   // qv already carries 1/sqrt(8)
+          atomicAdd(&dvs[(c * n + j) * 32 + pl], p * go[c]);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) dq[hb + ((long)c * n + i) * HW + pix] = dqv[c] * scale;
+    }
+  }
+  __syncthreads();
+  for (int it = tid; it < tile; it += 256) {
+    const int p = it & 31, cj = it >> 5;
+    if (pix0 + p < HW) {
+      dk[hb + (long)cj * HW + pix0 + p] = dks[it];
+      dv[hb + (long)cj * HW + pix0 + p] = dvs[it];
+    }
+  }
+}
+
+static int ew_grid(long total) {
+  long g = (total + 255) / 256;
+  return (int)(g < 8192 ? (g > 0 ? g : 1) : 8192);
+}
+
+// x, key: (B,C,n,H,W); preds: (B,n,H,W); outputs kstar (B,HW) int32, e/pm (B,HW), denom (B,n)
+extern "C" int dca_context_inject_fwd(const float* x, const float* preds, float* key, int* kstar, float* e, float* pm,
+                                      float* denom, int B, int C, int n, long HW, hipStream_t stream) {
+  DCA_REQUIRE(x && preds && key && kstar && e && pm && denom && B > 0 && C > 0 && n > 0 && HW > 0 && B <= 65535);
+  hipError_t err = hipMemsetAsync(denom, 0, (size_t)B * n * sizeof(float), stream);
+  if (err != hipSuccess) return (int)err;
+  hipLaunchKernelGGL(ctx_stats_kernel, dim3(cdiv(HW, 256), B), dim3(256), n * sizeof(float), stream, preds, kstar, e,
+                     pm, denom, n, HW);
+  const long total = (long)B * C * n * HW;
+  hipLaunchKernelGGL(ctx_scale_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, x, kstar, e, denom, key, C, n, HW,
+                     total);
+  return dca_launch_status();
+}
+
+// dkey -> dx (B,C,n,HW) and dpreds (B,n,HW); scratch dw (B,HW), T (B,n)
+extern "C" int dca_context_inject_bwd(const float* dkey, const float* x, const float* preds, const int* kstar,
+                                      const float* e, const float* pm, const float* denom, float* dx, float* dpreds,
+                                      float* dw, float* T, int B, int C, int n, long HW, hipStream_t stream) {
+  DCA_REQUIRE(dkey && x && preds && kstar && e && pm && denom && dx && dpreds && dw && T);
+  DCA_REQUIRE(B > 0 && C > 0 && n > 0 && HW > 0 && B <= 65535);
+  hipError_t err = hipMemsetAsync(T, 0, (size_t)B * n * sizeof(float), stream);
+  if (err != hipSuccess) return (int)err;
+  hipLaunchKernelGGL(ctx_bwd_reduce_kernel, dim3(cdiv(HW, 256), B), dim3(256), n * sizeof(float), stream, dkey, x,
+                     kstar, e, denom, dw, T, C, n, HW);
+  hipLaunchKernelGGL(ctx_bwd_preds_kernel, dim3(ew_grid((long)B * HW)), dim3(256), 0, stream, preds, kstar, e, pm,
+                     denom, dw, T, dpreds, n, HW, (long)B * HW);
+  const long total = (long)B * C * n * HW;
+  hipLaunchKernelGGL(ctx_scale_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, dkey, kstar, e, denom, dx, C, n, HW,
+                     total);
+  return dca_launch_status();
+}
+
+extern "C" int dca_disp_attention_fwd(const float* q, const float* k, const float* v, float* out, int B, int C, int n,
+                                      long HW, hipStream_t stream) {
+  DCA_REQUIRE(q && k && v && out && B > 0 && C > 0 && C % 8 == 0 && n > 0 && n <= 32 && HW > 0);
+  DCA_REQUIRE(C / 8 <= 65535 && B <= 65535);
+  const size_t lds = (size_t)2 * 8 * n * 32 * 4;
+  const dim3 grid(cdiv(HW, 32), C / 8, B);
+  const int qpt = (n + 7) / 8;
+#define LAUNCH(Q)                                                                                         \
+  hipLaunchKernelGGL(attn_fwd_kernel<Q>, grid, dim3(256), lds, stream, q, k, v, out, C, n, HW)
+  if (qpt == 1) LAUNCH(1);
+  else if (qpt == 2) LAUNCH(2);
+  else if (qpt == 3) LAUNCH(3);
+  else LAUNCH(4);
+#undef LAUNCH
+  return dca_launch_status();
+}
+
+extern "C" int dca_disp_attention_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq,
+                                      float* dk, float* dv, int B, int C, int n, long HW, hipStream_t stream) {
+  DCA_REQUIRE(q && k && v && dout && dq && dk && dv && B > 0 && C > 0 && C % 8 == 0 && n > 0 && n <= 32 && HW > 0);
+  DCA_REQUIRE(C / 8 <= 65535 && B <= 65535);
+  const size_t lds = (size_t)4 * 8 * n * 32 * 4;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(cdiv(HW, 32), C / 8, B), dim3(256), lds, stream, q, k, v, dout, dq, dk, dv,
+                     C, n, HW);
+  return dca_launch_status();
+}

@@ -1,0 +1,453 @@
+// 3D convolutions of the DCANet aggregation path on the CDNA4 matrix cores, exact fp32.
+//
+// Replaces (reference, PyTorch/ATen): nn.Conv3d / nn.ConvTranspose3d inside `convbn_3d`
+// (models/submodule.py:121-124), `dres0/dres1/classif*` (models/gwcnet_dca_g.py:141-168),
+// `cva.downsample/classify/fuse` (models/augment/cva.py:39-55), `Multi_Aggregation`
+// (cva.py:13-31) and the 1x1x1 projections of SelfAttention_bn.py:136-160.
+//
+// Layout: NCDHW fp32 in HBM (the reference's layout, so the Python boundary needs no permutes).
+// Contraction: v_mfma_f32_32x32x2_f32 with D[cout][voxel] += W[cout][k] * X[k][voxel]; the 32 MFMA
+// columns are 32 consecutive W positions, so both the LDS operand reads and the global stores are
+// contiguous along W (128 B per half wave).  K runs over (tap, cin) with the input halo tile and
+// the per-chunk weights staged in LDS.  The same three kernels serve the backward-data passes with
+// re-laid-out weights (see dca_conv3d_prep_weight).
+#include "dca_common.h"
+#include "../../include/dca_hip.h"
+
+struct ConvArgs {
+  const float* x;
+  const float* x2;
+  const float* wt;
+  float* y;
+  const float* scale;
+  const float* shift;
+  const float* res_pre;
+  const float* res_post;
+  float slope;
+  int N, Cin, Cout, CinPad;
+  int Di, Hi, Wi, Do, Ho, Wo;
+  int nTD, nTH, nTW;
+  long xs_n, x2s_n;  // batch strides (floats) of x / x2 (1x1 kernel only)
+};
+
+__device__ __forceinline__ float epilogue(const ConvArgs& a, float v, int co, long idx) {
+  if (a.scale) v = v * a.scale[co] + a.shift[co];
+  if (a.res_pre) v += a.res_pre[idx];
+  v = act_apply(v, a.slope);
+  if (a.res_post) v += a.res_post[idx];
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3x3x3, pad 1, stride S.  Block = 4 waves; output tile TD x TH x 32(W); each wave owns
+// NT = TD*TH/4 rows of 32 voxels and all CT*32 output channels.
+// ---------------------------------------------------------------------------------------------
+template <int S, int CT, int CK, int TD, int TH, bool VEC>
+__global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
+  constexpr int NT = TD * TH / 4;
+  constexpr int ID = (TD - 1) * S + 3, IH = (TH - 1) * S + 3, IW = 31 * S + 3;
+  constexpr int IWP = (S == 1) ? 40 : 68;
+  constexpr int CO = CT * 32;
+  constexpr int ROWS = CK * ID * IH;
+  constexpr int IN_ELEMS = ROWS * IWP;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* in_lds = smem;
+  float* w_lds = smem + IN_ELEMS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tw = bid % a.nTW; bid /= a.nTW;
+  const int th = bid % a.nTH; bid /= a.nTH;
+  const int td = bid % a.nTD;
+  const int n = bid / a.nTD;
+  const int d0 = td * TD, h0 = th * TH, w0 = tw * 32;
+  const int di0 = d0 * S - 1, hi0 = h0 * S - 1, wi0 = w0 * S - 1;
+
+  f32x16 acc[NT][CT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][ct][r] = 0.f;
+
+  int boff[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int r = wv * NT + t, dl = r / TH, hl = r % TH;
+    boff[t] = ((half * ID + dl * S) * IH + hl * S) * IWP + 3 + l31 * S;
+  }
+
+  for (int ci0 = 0; ci0 < a.CinPad; ci0 += CK) {
+    __syncthreads();
+    if (VEC) {
+      constexpr int QPR = 8 * S;
+      for (int it = tid; it < ROWS * QPR; it += 256) {
+        const int row = it / QPR, q = it % QPR;
+        const int c = row / (ID * IH), rem = row % (ID * IH), id = rem / IH, ih = rem % IH;
+        const int ci = ci0 + c, di = di0 + id, hi = hi0 + ih, wi = wi0 + 1 + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ci < a.Cin && (unsigned)di < (unsigned)a.Di && (unsigned)hi < (unsigned)a.Hi && wi < a.Wi)
+          v = *(const float4*)(a.x + ((((long)n * a.Cin + ci) * a.Di + di) * a.Hi + hi) * a.Wi + wi);
+        *(float4*)(in_lds + row * IWP + 4 + 4 * q) = v;
+      }
+      constexpr int NH = (S == 1) ? 2 : 1;
+      for (int it = tid; it < ROWS * NH; it += 256) {
+        const int row = it / NH, j = (it % NH) ? (IW - 1) : 0;
+        const int c = row / (ID * IH), rem = row % (ID * IH), id = rem / IH, ih = rem % IH;
+        const int ci = ci0 + c, di = di0 + id, hi = hi0 + ih, wi = wi0 + j;
+        float v = 0.f;
+        if (ci < a.Cin && (unsigned)di < (unsigned)a.Di && (unsigned)hi < (unsigned)a.Hi &&
+            (unsigned)wi < (unsigned)a.Wi)
+          v = a.x[((((long)n * a.Cin + ci) * a.Di + di) * a.Hi + hi) * a.Wi + wi];
+        in_lds[row * IWP + 3 + j] = v;
+      }
+    } else {
+      for (int it = tid; it < ROWS * IW; it += 256) {
+        const int row = it / IW, j = it % IW;
+        const int c = row / (ID * IH), rem = row % (ID * IH), id = rem / IH, ih = rem % IH;
+        const int ci = ci0 + c, di = di0 + id, hi = hi0 + ih, wi = wi0 + j;
+        float v = 0.f;
+        if (ci < a.Cin && (unsigned)di < (unsigned)a.Di && (unsigned)hi < (unsigned)a.Hi &&
+            (unsigned)wi < (unsigned)a.Wi)
+          v = a.x[((((long)n * a.Cin + ci) * a.Di + di) * a.Hi + hi) * a.Wi + wi];
+        in_lds[row * IWP + 3 + j] = v;
+      }
+    }
+    {
+      constexpr int WQ = CK * CO / 4;
+      for (int it = tid; it < 27 * WQ; it += 256) {
+        const int tap = it / WQ, q = it % WQ;
+        *(float4*)(w_lds + tap * CK * CO + 4 * q) =
+            *(const float4*)(a.wt + ((long)tap * a.CinPad + ci0) * CO + 4 * q);
+      }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int kd = 0; kd < 3; ++kd) {
+#pragma unroll 1
+      for (int kh = 0; kh < 3; ++kh) {
+        const float* inb = in_lds + (kd * IH + kh) * IWP;
+        const float* wb = w_lds + (kd * 3 + kh) * 3 * CK * CO + half * CO + l31;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+          for (int kk = 0; kk < CK / 2; ++kk) {
+            float av[CT];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) av[ct] = wb[(kw * CK + 2 * kk) * CO + ct * 32];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              const float bv = inb[boff[t] + kk * 2 * ID * IH * IWP + kw];
+#pragma unroll
+              for (int ct = 0; ct < CT; ++ct)
+                acc[t][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ct], bv, acc[t][ct], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  const int w = w0 + l31;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int r0 = wv * NT + t, d = d0 + r0 / TH, h = h0 + r0 % TH;
+    if (d >= a.Do || h >= a.Ho || w >= a.Wo) continue;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (co < a.Cout) {
+          const long idx = ((((long)n * a.Cout + co) * a.Do + d) * a.Ho + h) * a.Wo + w;
+          a.y[idx] = epilogue(a, acc[t][ct][r], co, idx);
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Transposed 3x3x3, stride 2, pad 1, output_padding 1 (out = 2*in).  out[o] += x[m] W[k] with
+// o = 2m - 1 + k: per dim, k=1 feeds even outputs from x[m]; k=0 / k=2 feed odd outputs 2m+1 from
+// x[m+1] / x[m].  Each wave owns one row of 32 coarse positions and keeps the 8 output-parity
+// classes in 8 accumulators; the 27 taps are distributed over them at compile time.
+// ---------------------------------------------------------------------------------------------
+template <int CK, bool VEC>
+__global__ __launch_bounds__(256, 2) void deconv3_mfma_kernel(ConvArgs a) {
+  constexpr int ID = 3, IH = 3, IWP = 40, CO = 32;
+  constexpr int ROWS = CK * ID * IH;
+  constexpr int IN_ELEMS = ROWS * IWP;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* in_lds = smem;
+  float* w_lds = smem + IN_ELEMS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tw = bid % a.nTW; bid /= a.nTW;
+  const int th = bid % a.nTH; bid /= a.nTH;
+  const int td = bid % a.nTD;
+  const int n = bid / a.nTD;
+  const int md0 = td * 2, mh0 = th * 2, mw0 = tw * 32;
+  const int mdl = wv >> 1, mhl = wv & 1;
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+  const int boff = ((half * ID + mdl) * IH + mhl) * IWP + 4 + l31;
+
+  for (int ci0 = 0; ci0 < a.CinPad; ci0 += CK) {
+    __syncthreads();
+    if (VEC) {
+      for (int it = tid; it < ROWS * 8; it += 256) {
+        const int row = it >> 3, q = it & 7;
+        const int c = row / 9, rem = row % 9, id = rem / 3, ih = rem % 3;
+        const int ci = ci0 + c, di = md0 + id, hi = mh0 + ih, wi = mw0 + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ci < a.Cin && di < a.Di && hi < a.Hi && wi < a.Wi)
+          v = *(const float4*)(a.x + ((((long)n * a.Cin + ci) * a.Di + di) * a.Hi + hi) * a.Wi + wi);
+        *(float4*)(in_lds + row * IWP + 4 + 4 * q) = v;
+      }
+      for (int row = tid; row < ROWS; row += 256) {
+        const int c = row / 9, rem = row % 9, id = rem / 3, ih = rem % 3;
+        const int ci = ci0 + c, di = md0 + id, hi = mh0 + ih, wi = mw0 + 32;
+        float v = 0.f;
+        if (ci < a.Cin && di < a.Di && hi < a.Hi && wi < a.Wi)
+          v = a.x[((((long)n * a.Cin + ci) * a.Di + di) * a.Hi + hi) * a.Wi + wi];
+        in_lds[row * IWP + 36] = v;
+      }
+    } else {
+      for (int it = tid; it < ROWS * 33; it += 256) {
+        const int row = it / 33, j = it % 33;
+        const int c = row / 9, rem = row % 9, id = rem / 3, ih = rem % 3;
+        const int ci = ci0 + c, di = md0 + id, hi = mh0 + ih, wi = mw0 + j;
+        float v = 0.f;
+        if (ci < a.Cin && di < a.Di && hi < a.Hi && wi < a.Wi)
+          v = a.x[((((long)n * a.Cin + ci) * a.Di + di) * a.Hi + hi) * a.Wi + wi];
+        in_lds[row * IWP + 4 + j] = v;
+      }
+    }
+    {
+      constexpr int WQ = CK * CO / 4;
+      for (int it = tid; it < 27 * WQ; it += 256) {
+        const int tap = it / WQ, q = it % WQ;
+        *(float4*)(w_lds + tap * CK * CO + 4 * q) =
+            *(const float4*)(a.wt + ((long)tap * a.CinPad + ci0) * CO + 4 * q);
+      }
+    }
+    __syncthreads();
+    const float* wb = w_lds + half * CO + l31;
+    const float* inb = in_lds + boff;
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int pc = ((kd != 1) * 2 + (kh != 1)) * 2 + (kw != 1);
+          const int off = ((kd == 0) * IH + (kh == 0)) * IWP + (kw == 0);
+          const int tap = (kd * 3 + kh) * 3 + kw;
+#pragma unroll
+          for (int kk = 0; kk < CK / 2; ++kk) {
+            const float av = wb[(tap * CK + 2 * kk) * CO];
+            const float bv = inb[kk * 2 * ID * IH * IWP + off];
+            acc[pc] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[pc], 0, 0, 0);
+          }
+        }
+  }
+
+  const int md = md0 + mdl, mh = mh0 + mhl, mw = mw0 + l31;
+  if (md < a.Di && mh < a.Hi && mw < a.Wi) {
+#pragma unroll
+    for (int pd = 0; pd < 2; ++pd)
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+        const int d = 2 * md + pd, h = 2 * mh + ph;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (co < a.Cout) {
+            const long idx = ((((long)n * a.Cout + co) * a.Do + d) * a.Ho + h) * a.Wo + 2 * mw;
+            float2 o;
+            o.x = epilogue(a, acc[(pd * 2 + ph) * 2 + 0][r], co, idx);
+            o.y = epilogue(a, acc[(pd * 2 + ph) * 2 + 1][r], co, idx + 1);
+            *(float2*)(a.y + idx) = o;
+          }
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1x1x1 convolution (pointwise GEMM), Cout <= 32, Cin = 32*NG taken from x (first 32) and x2.
+// Each wave streams groups of 128 consecutive voxels: lane (i, half) loads float4 x[ci=2kk+half]
+// [v0+4i..]; MFMA tile j is the voxel set {v0+4i+j}, so loads and stores are 16 B per lane.
+// The weight fragments stay in registers.
+// ---------------------------------------------------------------------------------------------
+template <int NG, bool VEC>
+__global__ __launch_bounds__(256) void conv1_mfma_kernel(ConvArgs a) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
+  const long DHW = (long)a.Do * a.Ho * a.Wo;
+  const long ngroups = (DHW + 127) / 128, total = (long)a.N * ngroups;
+  float aw[NG * 16];
+#pragma unroll
+  for (int kk = 0; kk < NG * 16; ++kk) aw[kk] = a.wt[(2 * kk + half) * 32 + l31];
+
+  for (long g = (long)blockIdx.x * 4 + wv; g < total; g += (long)gridDim.x * 4) {
+    const int n = (int)(g / ngroups);
+    const long v = (g % ngroups) * 128 + 4 * l31;
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+    for (int grp = 0; grp < NG; ++grp) {
+      const float* xp = (grp == 0 ? a.x + n * a.xs_n : a.x2 + n * a.x2s_n) + v;
+      float4 b[16];
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const float* p = xp + (long)(2 * kk + half) * DHW;
+        if (VEC) {
+          b[kk] = (v < DHW) ? *(const float4*)p : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+          b[kk].x = (v + 0 < DHW) ? p[0] : 0.f;
+          b[kk].y = (v + 1 < DHW) ? p[1] : 0.f;
+          b[kk].z = (v + 2 < DHW) ? p[2] : 0.f;
+          b[kk].w = (v + 3 < DHW) ? p[3] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const float w = aw[grp * 16 + kk];
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b[kk].x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b[kk].y, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b[kk].z, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b[kk].w, acc[3], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (co >= a.Cout) continue;
+      const long idx = ((long)n * a.Cout + co) * DHW + v;
+      if (VEC) {
+        if (v < DHW) {
+          float4 o;
+          o.x = epilogue(a, acc[0][r], co, idx + 0);
+          o.y = epilogue(a, acc[1][r], co, idx + 1);
+          o.z = epilogue(a, acc[2][r], co, idx + 2);
+          o.w = epilogue(a, acc[3][r], co, idx + 3);
+          *(float4*)(a.y + idx) = o;
+        }
+      } else {
+        if (v + 0 < DHW) a.y[idx + 0] = epilogue(a, acc[0][r], co, idx + 0);
+        if (v + 1 < DHW) a.y[idx + 1] = epilogue(a, acc[1][r], co, idx + 1);
+        if (v + 2 < DHW) a.y[idx + 2] = epilogue(a, acc[2][r], co, idx + 2);
+        if (v + 3 < DHW) a.y[idx + 3] = epilogue(a, acc[3][r], co, idx + 3);
+      }
+    }
+  }
+}
+
+// dst[tap][a][b] (a < Apad rows = contraction channels, b < Bpad = output channels, zero padded)
+// from a PyTorch weight: src_ab ? src[a][b][K] : src[b][a][K]; flip reverses the tap order.
+__global__ void prep_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int A, int Bn,
+                                   int Apad, int Bpad, int K, int src_ab, int flip) {
+  const int total = K * Apad * Bpad;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int tap = idx / (Apad * Bpad), ai = (idx / Bpad) % Apad, bi = idx % Bpad;
+    float v = 0.f;
+    if (ai < A && bi < Bn) {
+      const int st = flip ? K - 1 - tap : tap;
+      v = src_ab ? src[((long)ai * Bn + bi) * K + st] : src[((long)bi * A + ai) * K + st];
+    }
+    dst[idx] = v;
+  }
+}
+
+template <typename KernelT>
+static int launch_conv(KernelT kernel, const ConvArgs& a, int grid, size_t lds, hipStream_t stream) {
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, stream, a);
+  return dca_launch_status();
+}
+
+extern "C" int dca_conv3d_prep_weight(const float* w, float* wt, int A, int B, int Apad, int Bpad, int K,
+                                      int src_ab, int flip, hipStream_t stream) {
+  DCA_REQUIRE(w && wt && A > 0 && B > 0 && Apad >= A && Bpad >= B && (K == 1 || K == 27));
+  const int total = K * Apad * Bpad;
+  hipLaunchKernelGGL(prep_weight_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, w, wt, A, B, Apad, Bpad, K,
+                     src_ab, flip);
+  return dca_launch_status();
+}
+
+extern "C" int dca_conv3d_forward(const float* x, const float* x2, const float* wt, float* y, const float* scale,
+                                  const float* shift, const float* res_pre, const float* res_post, float slope,
+                                  int N, int Cin, int C1, int Cout, int CinPad, int Di, int Hi, int Wi, int Do,
+                                  int Ho, int Wo, int ksize, int stride, int transposed, hipStream_t stream) {
+  DCA_REQUIRE(x && wt && y && N > 0 && Cin > 0 && Cout > 0 && CinPad >= Cin);
+  DCA_REQUIRE((scale == nullptr) == (shift == nullptr));
+  ConvArgs a;
+  a.x = x; a.x2 = x2; a.wt = wt; a.y = y; a.scale = scale; a.shift = shift;
+  a.res_pre = res_pre; a.res_post = res_post; a.slope = slope;
+  a.N = N; a.Cin = Cin; a.Cout = Cout; a.CinPad = CinPad;
+  a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Do = Do; a.Ho = Ho; a.Wo = Wo;
+  a.nTD = a.nTH = a.nTW = 1; a.xs_n = a.x2s_n = 0;
+  const bool aligned = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)wt) & 15) == 0;
+
+  if (ksize == 1) {
+    DCA_REQUIRE(stride == 1 && !transposed && Cout <= 32 && Di == Do && Hi == Ho && Wi == Wo);
+    const long DHW = (long)Do * Ho * Wo;
+    int NG;
+    if (x2) {
+      DCA_REQUIRE(C1 == 32 && Cin == 64 && CinPad == 64);
+      NG = 2; a.xs_n = 32 * DHW; a.x2s_n = 32 * DHW;
+    } else {
+      DCA_REQUIRE((Cin == 32 && CinPad == 32) || (Cin == 64 && CinPad == 64));
+      NG = Cin / 32; a.xs_n = (long)Cin * DHW; a.x2s_n = a.xs_n; a.x2 = x + 32 * DHW;
+    }
+    const bool vec = aligned && (DHW % 4 == 0) && ((((uintptr_t)a.x2) & 15) == 0);
+    const long total = (long)N * ((DHW + 127) / 128);
+    const int grid = (int)((total + 3) / 4 < 2048 ? (total + 3) / 4 : 2048);
+    if (NG == 1) return vec ? launch_conv(conv1_mfma_kernel<1, true>, a, grid, 0, stream)
+                            : launch_conv(conv1_mfma_kernel<1, false>, a, grid, 0, stream);
+    return vec ? launch_conv(conv1_mfma_kernel<2, true>, a, grid, 0, stream)
+               : launch_conv(conv1_mfma_kernel<2, false>, a, grid, 0, stream);
+  }
+  DCA_REQUIRE(ksize == 3 && x2 == nullptr);
+  const bool vec = aligned && (Wi % 4 == 0);
+  if (transposed) {
+    DCA_REQUIRE(stride == 2 && Cout <= 32 && Do == 2 * Di && Ho == 2 * Hi && Wo == 2 * Wi && CinPad % 8 == 0);
+    a.nTD = cdiv(Di, 2); a.nTH = cdiv(Hi, 2); a.nTW = cdiv(Wi, 32);
+    const int grid = N * a.nTD * a.nTH * a.nTW;
+    const size_t lds = (size_t)(8 * 9 * 40 + 27 * 8 * 32) * 4;
+    return vec ? launch_conv(deconv3_mfma_kernel<8, true>, a, grid, lds, stream)
+               : launch_conv(deconv3_mfma_kernel<8, false>, a, grid, lds, stream);
+  }
+  DCA_REQUIRE(Cout <= 64 && CinPad % 8 == 0);
+  if (stride == 1) {
+    DCA_REQUIRE(Do == Di && Ho == Hi && Wo == Wi);
+    a.nTD = cdiv(Do, 2); a.nTH = cdiv(Ho, 8); a.nTW = cdiv(Wo, 32);
+    const int grid = N * a.nTD * a.nTH * a.nTW;
+    if (Cout <= 32) {
+      const size_t lds = (size_t)(8 * 4 * 10 * 40 + 27 * 8 * 32) * 4;
+      return vec ? launch_conv(conv3_mfma_kernel<1, 1, 8, 2, 8, true>, a, grid, lds, stream)
+                 : launch_conv(conv3_mfma_kernel<1, 1, 8, 2, 8, false>, a, grid, lds, stream);
+    }
+    const size_t lds = (size_t)(4 * 4 * 10 * 40 + 27 * 4 * 64) * 4;
+    return vec ? launch_conv(conv3_mfma_kernel<1, 2, 4, 2, 8, true>, a, grid, lds, stream)
+               : launch_conv(conv3_mfma_kernel<1, 2, 4, 2, 8, false>, a, grid, lds, stream);
+  }
+  DCA_REQUIRE(stride == 2 && Do == (Di + 1) / 2 && Ho == (Hi + 1) / 2 && Wo == (Wi + 1) / 2);
+  a.nTD = cdiv(Do, 2); a.nTH = cdiv(Ho, 4); a.nTW = cdiv(Wo, 32);
+  const int grid = N * a.nTD * a.nTH * a.nTW;
+  const size_t lds = (size_t)(4 * 5 * 9 * 68 + 27 * 4 * 64) * 4;
+  return vec ? launch_conv(conv3_mfma_kernel<2, 2, 4, 2, 4, true>, a, grid, lds, stream)
+             : launch_conv(conv3_mfma_kernel<2, 2, 4, 2, 4, false>, a, grid, lds, stream);
+}

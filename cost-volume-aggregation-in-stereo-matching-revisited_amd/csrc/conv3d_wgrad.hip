@@ -1,0 +1,309 @@
+// Weight gradients of the 3D convolutions on the fp32 matrix cores (gfx950).
+//
+// Replaces the autograd weight-gradient of nn.Conv3d / nn.ConvTranspose3d on the aggregation path
+// (reference modules: models/submodule.py:121-124, models/augment/cva.py:13-55).
+//
+//   dW[cy][cx][k] = sum_{n, o} dy[n][cy][o] * x[n][cx][S*o - 1 + k]        (3x3x3, pad 1, stride S)
+//
+// As an MFMA contraction the reduction (K) axis is the voxel index: D[cy][cx] += A[cy][v] B[v][cx]
+// with v_mfma_f32_32x32x2_f32 (two voxels per instruction).  A workgroup stages a dy tile
+// [32 cy][TD*TH*32 voxels] and the matching x halo tile [32 cx][...] in LDS with ODD channel
+// pitches (lanes index channels, so an odd pitch makes the operand reads conflict free), the 27
+// taps are split over the 4 waves (7 accumulators each), and persistent workgroups keep their
+// accumulators over many tiles, writing one partial slab each; a small second kernel sums the
+// slabs in a fixed order (deterministic, no float atomics).
+//
+// The transposed convolution's weight gradient is the same reduction with the roles of the two
+// tensors exchanged (dWt[ci][co][k] = sum_m x[ci][m] dy[co][2m-1+k]); see dca_hip.h.
+#include "dca_common.h"
+#include "../../include/dca_hip.h"
+
+struct WgArgs {
+  const float* x;
+  const float* dy;
+  float* part;
+  int N, Cx, Cy, Di, Hi, Wi, Do, Ho, Wo;
+  int nTD, nTH, nTW, ntiles, nCxT;
+  int vecx, vecy;
+};
+
+template <int S>
+__global__ __launch_bounds__(256, 1) void wgrad3_kernel(WgArgs a) {
+  constexpr int TD = (S == 1) ? 2 : 1, TH = (S == 1) ? 4 : 2;
+  constexpr int NR = TD * TH, NV = NR * 32;
+  constexpr int ID = (TD - 1) * S + 3, IH = (TH - 1) * S + 3, IW = 31 * S + 3;
+  constexpr int IWP = (S == 1) ? 40 : 68;
+  constexpr int XP = ID * IH * IWP + 1;  // odd
+  constexpr int YP = NV + 1;             // odd
+  static_assert((XP & 1) && (YP & 1), "odd pitches");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;
+  float* ys = smem + 32 * XP;
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  const int cyT = blockIdx.y / a.nCxT, cxT = blockIdx.y % a.nCxT;
+  const int cy0 = cyT * 32, cx0 = cxT * 32;
+
+  f32x16 acc[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  int toff[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    int tap = wv + 4 * j;
+    if (tap > 26) tap = 26;
+    toff[j] = ((tap / 9) * IH + (tap / 3) % 3) * IWP + tap % 3;
+  }
+  const float* xb = xs + l31 * XP + 3 + half * S;
+  const float* yb = ys + l31 * YP + half;
+
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    int t = tile;
+    const int tw = t % a.nTW; t /= a.nTW;
+    const int th = t % a.nTH; t /= a.nTH;
+    const int td = t % a.nTD;
+    const int n = t / a.nTD;
+    const int d0 = td * TD, h0 = th * TH, w0 = tw * 32;
+    const int di0 = d0 * S - 1, hi0 = h0 * S - 1, wi0 = w0 * S - 1;
+    __syncthreads();
+    // ---- x halo tile
+    constexpr int ROWS = 32 * ID * IH;
+    if (a.vecx) {
+      constexpr int QPR = 8 * S;
+      for (int it = tid; it < ROWS * QPR; it += 256) {
+        const int row = it / QPR, q = it % QPR;
+        const int c = row / (ID * IH), rem = row % (ID * IH), id = rem / IH, ih = rem % IH;
+        const int ci = cx0 + c, di = di0 + id, hi = hi0 + ih, wi = wi0 + 1 + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ci < a.Cx && (unsigned)di < (unsigned)a.Di && (unsigned)hi < (unsigned)a.Hi && wi < a.Wi)
+          v = *(const float4*)(a.x + ((((long)n * a.Cx + ci) * a.Di + di) * a.Hi + hi) * a.Wi + wi);
+        float* dst = xs + c * XP + rem * IWP + 4 + 4 * q;
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+      }
+      constexpr int NH = (S == 1) ? 2 : 1;
+      for (int it = tid; it < ROWS * NH; it += 256) {
+        const int row = it / NH, j = (it % NH) ? (IW - 1) : 0;
+        const int c = row / (ID * IH), rem = row % (ID * IH), id = rem / IH, ih = rem % IH;
+        const int ci = cx0 + c, di = di0 + id, hi = hi0 + ih, wi = wi0 + j;
+        float v = 0.f;
+        if (ci < a.Cx && (unsigned)di < (unsigned)a.Di && (unsigned)hi < (unsigned)a.Hi &&
+            (unsigned)wi < (unsigned)a.Wi)
+          v = a.x[((((long)n * a.Cx + ci) * a.Di + di) * a.Hi + hi) * a.Wi + wi];
+        xs[c * XP + rem * IWP + 3 + j] = v;
+      }
+    } else {
+      for (int it = tid; it < ROWS * IW; it += 256) {
+        const int row = it / IW, j = it % IW;
+        const int c = row / (ID * IH), rem = row % (ID * IH), id = rem / IH, ih = rem % IH;
+        const int ci = cx0 + c, di = di0 + id, hi = hi0 + ih, wi = wi0 + j;
+        float v = 0.f;
+        if (ci < a.Cx && (unsigned)di < (unsigned)a.Di && (unsigned)hi < (unsigned)a.Hi &&
+            (unsigned)wi < (unsigned)a.Wi)
+          v = a.x[((((long)n * a.Cx + ci) * a.Di + di) * a.Hi + hi) * a.Wi + wi];
+        xs[c * XP + rem * IWP + 3 + j] = v;
+      }
+    }
+    // ---- dy tile
+    if (a.vecy) {
+      for (int it = tid; it < 32 * NR * 8; it += 256) {
+        const int q = it & 7, row = (it >> 3) % NR, c = it / (8 * NR);
+        const int co = cy0 + c, d = d0 + row / TH, h = h0 + row % TH, w = w0 + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (co < a.Cy && d < a.Do && h < a.Ho && w < a.Wo)
+          v = *(const float4*)(a.dy + ((((long)n * a.Cy + co) * a.Do + d) * a.Ho + h) * a.Wo + w);
+        float* dst = ys + c * YP + row * 32 + 4 * q;
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+      }
+    } else {
+      for (int it = tid; it < 32 * NV; it += 256) {
+        const int wl = it & 31, row = (it >> 5) % NR, c = it / NV;
+        const int co = cy0 + c, d = d0 + row / TH, h = h0 + row % TH, w = w0 + wl;
+        float v = 0.f;
+        if (co < a.Cy && d < a.Do && h < a.Ho && w < a.Wo)
+          v = a.dy[((((long)n * a.Cy + co) * a.Do + d) * a.Ho + h) * a.Wo + w];
+        ys[c * YP + row * 32 + wl] = v;
+      }
+    }
+    __syncthreads();
+    // ---- contraction over the tile's voxels, two per MFMA
+#pragma unroll 1
+    for (int row = 0; row < NR; ++row) {
+      const int dl = row / TH, hl = row % TH;
+      const float* xr = xb + ((dl * S) * IH + hl * S) * IWP;
+      const float* yr = yb + row * 32;
+#pragma unroll 4
+      for (int wp = 0; wp < 16; ++wp) {
+        const float av = yr[2 * wp];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+          const float bv = xr[2 * wp * S + toff[j]];
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- partial slab: part[((blk*nChanTiles + chanTile)*27 + tap)*1024 + cy*32 + cx]
+  const long slab = ((long)blockIdx.x * gridDim.y + blockIdx.y) * 27;
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int tap = wv + 4 * j;
+    if (tap > 26) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int cy = (r & 3) + 8 * (r >> 2) + 4 * half;
+      a.part[(slab + tap) * 1024 + cy * 32 + l31] = acc[j][r];
+    }
+  }
+}
+
+// 1x1x1: dW[cy][cx] = sum_v dy[cy][v] x[cx][v]; tile = 256 voxels, each wave contracts 64 of them.
+__global__ __launch_bounds__(256, 1) void wgrad1_kernel(WgArgs a) {
+  constexpr int NV = 256, P = NV + 1;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;
+  float* ys = smem + 32 * P;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  const int cyT = blockIdx.y / a.nCxT, cxT = blockIdx.y % a.nCxT;
+  const int cy0 = cyT * 32, cx0 = cxT * 32;
+  const long DHW = (long)a.Do * a.Ho * a.Wo;
+  const long tiles_per_n = (DHW + NV - 1) / NV;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (long tile = blockIdx.x; tile < (long)a.N * tiles_per_n; tile += gridDim.x) {
+    const int n = (int)(tile / tiles_per_n);
+    const long v0 = (tile % tiles_per_n) * NV;
+    __syncthreads();
+    if (a.vecx) {
+      for (int it = tid; it < 32 * 64; it += 256) {
+        const int q = it & 63, c = it >> 6;
+        const long v = v0 + 4 * q;
+        float4 vx = make_float4(0.f, 0.f, 0.f, 0.f), vy = vx;
+        if (v < DHW) {
+          if (cx0 + c < a.Cx) vx = *(const float4*)(a.x + ((long)n * a.Cx + cx0 + c) * DHW + v);
+          if (cy0 + c < a.Cy) vy = *(const float4*)(a.dy + ((long)n * a.Cy + cy0 + c) * DHW + v);
+        }
+        float* dx = xs + c * P + 4 * q;
+        float* dyp = ys + c * P + 4 * q;
+        dx[0] = vx.x; dx[1] = vx.y; dx[2] = vx.z; dx[3] = vx.w;
+        dyp[0] = vy.x; dyp[1] = vy.y; dyp[2] = vy.z; dyp[3] = vy.w;
+      }
+    } else {
+      for (int it = tid; it < 32 * NV; it += 256) {
+        const int vl = it & 255, c = it >> 8;
+        const long v = v0 + vl;
+        xs[c * P + vl] = (v < DHW && cx0 + c < a.Cx) ? a.x[((long)n * a.Cx + cx0 + c) * DHW + v] : 0.f;
+        ys[c * P + vl] = (v < DHW && cy0 + c < a.Cy) ? a.dy[((long)n * a.Cy + cy0 + c) * DHW + v] : 0.f;
+      }
+    }
+    __syncthreads();
+    const float* xr = xs + l31 * P + wv * 64 + half;
+    const float* yr = ys + l31 * P + wv * 64 + half;
+#pragma unroll 8
+    for (int p = 0; p < 32; ++p) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(yr[2 * p], xr[2 * p], acc, 0, 0, 0);
+  }
+  // reduce the 4 waves through LDS, then one slab per workgroup
+  __syncthreads();
+  float* red = smem;  // [4][1024]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wv * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[r];
+  __syncthreads();
+  const long slab = (long)blockIdx.x * gridDim.y + blockIdx.y;
+  for (int i = tid; i < 1024; i += 256)
+    a.part[slab * 1024 + i] = (red[i] + red[1024 + i]) + (red[2048 + i] + red[3072 + i]);
+}
+
+// dw[cy*s_cy + cx*s_cx + tap] = sum_blk part[((blk*nCT + ct)*K + tap)*1024 + (cy%32)*32 + cx%32]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nblk, int nCxT,
+                                    int nCT, int K, int Cy, int Cx, long s_cy, long s_cx) {
+  const int total = Cy * Cx * K;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int tap = idx % K, cx = (idx / K) % Cx, cy = idx / (K * Cx);
+    const int ct = (cy >> 5) * nCxT + (cx >> 5);
+    const float* p = part + ((long)ct * K + tap) * 1024 + (cy & 31) * 32 + (cx & 31);
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += p[(long)b * nCT * K * 1024];
+    dw[cy * s_cy + cx * s_cx + tap] = s;
+  }
+}
+
+static int wg_workers(int ntiles, int nCT) {
+  int w = 256 / nCT;
+  if (w < 1) w = 1;
+  return ntiles < w ? ntiles : w;
+}
+
+static void wg_geometry(int ksize, int stride, int N, int Do, int Ho, int Wo, int* nTD, int* nTH, int* nTW,
+                        long* ntiles) {
+  if (ksize == 1) {
+    const long DHW = (long)Do * Ho * Wo;
+    *nTD = *nTH = *nTW = 1;
+    *ntiles = (long)N * ((DHW + 255) / 256);
+    return;
+  }
+  const int TD = stride == 1 ? 2 : 1, TH = stride == 1 ? 4 : 2;
+  *nTD = cdiv(Do, TD); *nTH = cdiv(Ho, TH); *nTW = cdiv(Wo, 32);
+  *ntiles = (long)N * *nTD * *nTH * *nTW;
+}
+
+// number of floats of scratch `part` needed by dca_conv3d_wgrad for this problem
+extern "C" long dca_conv3d_wgrad_workspace(int N, int Cx, int Cy, int Do, int Ho, int Wo, int ksize, int stride) {
+  int nTD, nTH, nTW; long ntiles;
+  wg_geometry(ksize, stride, N, Do, Ho, Wo, &nTD, &nTH, &nTW, &ntiles);
+  const int nCT = cdiv(Cx, 32) * cdiv(Cy, 32);
+  const int K = ksize == 1 ? 1 : 27;
+  return (long)wg_workers((int)(ntiles < 65535 ? ntiles : 65535), nCT) * nCT * K * 1024;
+}
+
+extern "C" int dca_conv3d_wgrad(const float* x, const float* dy, float* part, float* dw, int N, int Cx, int Cy, int Di,
+                                int Hi, int Wi, int Do, int Ho, int Wo, int ksize, int stride, long s_cy, long s_cx,
+                                hipStream_t stream) {
+  DCA_REQUIRE(x && dy && part && dw && N > 0 && Cx > 0 && Cy > 0 && (ksize == 1 || ksize == 3));
+  DCA_REQUIRE(stride == 1 || (stride == 2 && ksize == 3));
+  if (ksize == 1) DCA_REQUIRE(Di == Do && Hi == Ho && Wi == Wo);
+  else DCA_REQUIRE(Do == (Di + stride - 1) / stride && Ho == (Hi + stride - 1) / stride &&
+                   Wo == (Wi + stride - 1) / stride);
+  WgArgs a;
+  a.x = x; a.dy = dy; a.part = part; a.N = N; a.Cx = Cx; a.Cy = Cy;
+  a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Do = Do; a.Ho = Ho; a.Wo = Wo;
+  long ntiles;
+  wg_geometry(ksize, stride, N, Do, Ho, Wo, &a.nTD, &a.nTH, &a.nTW, &ntiles);
+  DCA_REQUIRE(ntiles < (1L << 31));
+  a.ntiles = (int)ntiles;
+  a.nCxT = cdiv(Cx, 32);
+  const int nCT = a.nCxT * cdiv(Cy, 32);
+  const int K = ksize == 1 ? 1 : 27;
+  const int nblk = wg_workers((int)(ntiles < 65535 ? ntiles : 65535), nCT);
+  const dim3 grid(nblk, nCT);
+  if (ksize == 1) {
+    const long DHW = (long)Do * Ho * Wo;
+    a.vecx = a.vecy = (DHW % 4 == 0) && ((((uintptr_t)x | (uintptr_t)dy) & 15) == 0);
+    const size_t lds = (size_t)2 * 32 * 257 * 4;
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(wgrad1_kernel, grid, dim3(256), lds, stream, a);
+  } else {
+    a.vecx = (Wi % 4 == 0) && (((uintptr_t)x & 15) == 0);
+    a.vecy = (Wo % 4 == 0) && (((uintptr_t)dy & 15) == 0);
+    if (stride == 1) {
+      const size_t lds = (size_t)(32 * (4 * 6 * 40 + 1) + 32 * 257) * 4;
+      hipError_t e = hipFuncSetAttribute((const void*)wgrad3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds);
+      if (e != hipSuccess) return (int)e;
+      hipLaunchKernelGGL(wgrad3_kernel<1>, grid, dim3(256), lds, stream, a);
+    } else {
+      const size_t lds = (size_t)(32 * (3 * 5 * 68 + 1) + 32 * 65) * 4;
+      hipError_t e = hipFuncSetAttribute((const void*)wgrad3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds);
+      if (e != hipSuccess) return (int)e;
+      hipLaunchKernelGGL(wgrad3_kernel<2>, grid, dim3(256), lds, stream, a);
+    }
+  }
+  int st = dca_launch_status();
+  if (st) return st;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((long)Cy * Cx * K, 256)), dim3(256), 0, stream, part, dw, nblk,
+                     a.nCxT, nCT, K, Cy, Cx, s_cy, s_cx);
+  return dca_launch_status();
+}

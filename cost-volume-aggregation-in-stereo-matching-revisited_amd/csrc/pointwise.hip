@@ -1,0 +1,414 @@
+// Bandwidth-bound glue of the DCANet aggregation path: BatchNorm3d (batch statistics, affine +
+// activation + residual apply, backward), AvgPool3d(3,2,1) and trilinear up-sampling.
+//
+// Replaces (reference): nn.BatchNorm3d inside convbn_3d (models/submodule.py:121-124) with the
+// ReLU / LeakyReLU(0.1) / residual adds that follow it (models/gwcnet_dca_g.py:141-148,225,229;
+// models/augment/cva.py:26-31,55; SelfAttention_bn.py:139-143), nn.AvgPool3d (cva.py:39) and
+// F.interpolate(mode='trilinear', align_corners=False) (cva.py:64, gwcnet_dca_g.py:251-261).
+//
+// All tensors are NC[D]HW fp32: channel c owns contiguous runs of S = D*H*W floats per sample, so
+// every kernel streams 16 B per lane along S.
+#include "dca_common.h"
+#include "../../include/dca_hip.h"
+
+// ------------------------------------------------------------------------------------ BN statistics
+// part[(c*nchunk + chunk)*2 + {0,1}] = (sum x, sum x^2) over all samples and one chunk of S (double).
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, double* __restrict__ part, int N,
+                                                       int C, long S, int nchunk, long chunk_len, int vec) {
+  const int c = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
+  const long s0 = ch * chunk_len, s1 = min(S, s0 + chunk_len);
+  float s = 0.f, ss = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const float* p = x + ((long)n * C + c) * S;
+    if (vec) {
+      for (long i = s0 + 4 * tid; i < s1; i += 1024) {
+        const float4 v = *(const float4*)(p + i);
+        s += (v.x + v.y) + (v.z + v.w);
+        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      }
+    } else {
+      for (long i = s0 + tid; i < s1; i += 256) {
+        const float v = p[i];
+        s += v;
+        ss += v * v;
+      }
+    }
+  }
+  double ds = wave_sum_d((double)s), dss = wave_sum_d((double)ss);
+  __shared__ double red[8];
+  if ((tid & 63) == 0) { red[(tid >> 6) * 2] = ds; red[(tid >> 6) * 2 + 1] = dss; }
+  __syncthreads();
+  if (tid == 0) {
+    part[((long)c * nchunk + ch) * 2 + 0] = red[0] + red[2] + red[4] + red[6];
+    part[((long)c * nchunk + ch) * 2 + 1] = red[1] + red[3] + red[5] + red[7];
+  }
+}
+
+// stats[0..C) mean, [C..2C) invstd, [2C..3C) scale = gamma*invstd, [3C..4C) shift = beta - mean*scale.
+// training: batch statistics (+ running-stat update, momentum m, unbiased variance); otherwise running stats.
+__global__ void bn_finalize_kernel(const double* __restrict__ part, int nchunk, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
+                                   float eps, int training, float* __restrict__ stats, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mean, var;
+  if (training) {
+    double s = 0.0, ss = 0.0;
+    for (int i = 0; i < nchunk; ++i) {
+      s += part[((long)c * nchunk + i) * 2 + 0];
+      ss += part[((long)c * nchunk + i) * 2 + 1];
+    }
+    const double m = s / count;
+    double v = ss / count - m * m;
+    if (v < 0.0) v = 0.0;
+    mean = (float)m;
+    var = (float)v;
+    if (running_mean) {
+      const double unb = count > 1.0 ? v * count / (count - 1.0) : v;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+  } else {
+    mean = running_mean[c];
+    var = running_var[c];
+  }
+  const float invstd = 1.0f / sqrtf(var + eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  stats[c] = mean;
+  stats[C + c] = invstd;
+  stats[2 * C + c] = g * invstd;
+  stats[3 * C + c] = b - mean * g * invstd;
+}
+
+// z = act(scale[c]*y + shift[c] + res_pre) + res_post
+__global__ void bn_apply_kernel(const float* __restrict__ y, const float* __restrict__ stats,
+                                const float* __restrict__ res_pre, const float* __restrict__ res_post,
+                                float* __restrict__ z, int C, long S, long total, float slope, int vec) {
+  const float* scale = stats + 2 * C;
+  const float* shift = stats + 3 * C;
+  if (vec) {
+    const long total4 = total >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+      const int c = (int)((i * 4 / S) % C);
+      const float sc = scale[c], sh = shift[c];
+      float4 v = ((const float4*)y)[i];
+      v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+      if (res_pre) { const float4 r = ((const float4*)res_pre)[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+      v.x = act_apply(v.x, slope); v.y = act_apply(v.y, slope); v.z = act_apply(v.z, slope); v.w = act_apply(v.w, slope);
+      if (res_post) { const float4 r = ((const float4*)res_post)[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+      ((float4*)z)[i] = v;
+    }
+  } else {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+      const int c = (int)((i / S) % C);
+      float v = y[i] * scale[c] + shift[c];
+      if (res_pre) v += res_pre[i];
+      v = act_apply(v, slope);
+      if (res_post) v += res_post[i];
+      z[i] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ BN backward
+// u = scale*y + shift (+res_pre); g = dz * (u > 0 ? 1 : slope); xhat = (y - mean)*invstd
+// part = per-(channel, chunk) double sums of (g, g*xhat).
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dz, const float* __restrict__ y,
+                                                            const float* __restrict__ res_pre,
+                                                            const float* __restrict__ stats,
+                                                            double* __restrict__ part, int N, int C, long S,
+                                                            int nchunk, long chunk_len, float slope) {
+  const int c = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
+  const long s0 = ch * chunk_len, s1 = min(S, s0 + chunk_len);
+  const float mean = stats[c], invstd = stats[C + c], sc = stats[2 * C + c], sh = stats[3 * C + c];
+  float a0 = 0.f, a1 = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const long base = ((long)n * C + c) * S;
+    for (long i = s0 + tid; i < s1; i += 256) {
+      const float yv = y[base + i];
+      float u = yv * sc + sh;
+      if (res_pre) u += res_pre[base + i];
+      const float g = dz[base + i] * (u > 0.f ? 1.f : slope);
+      a0 += g;
+      a1 += g * (yv - mean) * invstd;
+    }
+  }
+  double d0 = wave_sum_d((double)a0), d1 = wave_sum_d((double)a1);
+  __shared__ double red[8];
+  if ((tid & 63) == 0) { red[(tid >> 6) * 2] = d0; red[(tid >> 6) * 2 + 1] = d1; }
+  __syncthreads();
+  if (tid == 0) {
+    part[((long)c * nchunk + ch) * 2 + 0] = red[0] + red[2] + red[4] + red[6];
+    part[((long)c * nchunk + ch) * 2 + 1] = red[1] + red[3] + red[5] + red[7];
+  }
+}
+
+// dgb[0..C) = dgamma, dgb[C..2C) = dbeta, dgb[2C..3C) = dbeta/count, dgb[3C..4C) = dgamma/count
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nchunk, double count,
+                                       float* __restrict__ dgb, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int i = 0; i < nchunk; ++i) {
+    s0 += part[((long)c * nchunk + i) * 2 + 0];
+    s1 += part[((long)c * nchunk + i) * 2 + 1];
+  }
+  dgb[c] = (float)s1;
+  dgb[C + c] = (float)s0;
+  dgb[2 * C + c] = (float)(s0 / count);
+  dgb[3 * C + c] = (float)(s1 / count);
+}
+
+// dy = scale * (g - [training](dbeta/count + xhat*dgamma/count)); optionally g_out = g (grad of res_pre).
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ y,
+                                    const float* __restrict__ res_pre, const float* __restrict__ stats,
+                                    const float* __restrict__ dgb, float* __restrict__ dy, float* __restrict__ g_out,
+                                    int C, long S, long total, float slope, int training) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)((i / S) % C);
+    const float mean = stats[c], invstd = stats[C + c], sc = stats[2 * C + c], sh = stats[3 * C + c];
+    const float yv = y[i];
+    float u = yv * sc + sh;
+    if (res_pre) u += res_pre[i];
+    const float g = dz[i] * (u > 0.f ? 1.f : slope);
+    float v = g;
+    if (training) v -= dgb[2 * C + c] + (yv - mean) * invstd * dgb[3 * C + c];
+    dy[i] = v * sc;
+    if (g_out) g_out[i] = g;
+  }
+}
+
+// ------------------------------------------------------------------------------------ AvgPool3d(3, 2, 1)
+__global__ void avgpool3d_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long NC, int Di, int Hi,
+                                     int Wi, int Do, int Ho, int Wo) {
+  const long total = NC * Do * Ho * Wo;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int ow = idx % Wo;
+    long t = idx / Wo;
+    const int oh = t % Ho; t /= Ho;
+    const int od = t % Do;
+    const long nc = t / Do;
+    const float* p = x + nc * Di * Hi * Wi;
+    float s = 0.f;
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) {
+      const int d = 2 * od - 1 + kd;
+      if ((unsigned)d >= (unsigned)Di) continue;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int h = 2 * oh - 1 + kh;
+        if ((unsigned)h >= (unsigned)Hi) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int w = 2 * ow - 1 + kw;
+          if ((unsigned)w < (unsigned)Wi) s += p[((long)d * Hi + h) * Wi + w];
+        }
+      }
+    }
+    y[idx] = s * (1.0f / 27.0f);  // count_include_pad=True: always /27
+  }
+}
+
+__global__ void avgpool3d_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, long NC, int Di, int Hi,
+                                     int Wi, int Do, int Ho, int Wo) {
+  const long total = NC * Di * Hi * Wi;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int w = idx % Wi;
+    long t = idx / Wi;
+    const int h = t % Hi; t /= Hi;
+    const int d = t % Di;
+    const long nc = t / Di;
+    const float* p = gy + nc * Do * Ho * Wo;
+    // outputs o with 2o-1+k = i, k in {0,1,2}: o in [ceil((i-1)/2), floor((i+1)/2)]
+    const int d0 = d >> 1, d1 = (d + 1) >> 1, h0 = h >> 1, h1 = (h + 1) >> 1, w0 = w >> 1, w1 = (w + 1) >> 1;
+    float s = 0.f;
+    for (int od = d0; od <= d1; ++od) {
+      if (od >= Do) continue;
+      for (int oh = h0; oh <= h1; ++oh) {
+        if (oh >= Ho) continue;
+        for (int ow = w0; ow <= w1; ++ow)
+          if (ow < Wo) s += p[((long)od * Ho + oh) * Wo + ow];
+      }
+    }
+    gx[idx] = s * (1.0f / 27.0f);
+  }
+}
+
+// ------------------------------------------------------------------------------------ trilinear
+// align_corners=False, integer scale s: src = (dst+0.5)/s - 0.5 clamped at 0 (ATen area_pixel_compute_source_index)
+__device__ __forceinline__ void lin_src(int o, float rs, int n, int& i0, int& i1, float& l0, float& l1) {
+  float src = rs * ((float)o + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  i0 = (int)src;
+  i1 = i0 + (i0 < n - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.f - l1;
+}
+
+__global__ void trilinear_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long NC, int Di, int Hi,
+                                     int Wi, int s) {
+  const int Do = Di * s, Ho = Hi * s, Wo = Wi * s;
+  const float rs = 1.0f / (float)s;
+  const long total = NC * Do * Ho * Wo;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int ow = idx % Wo;
+    long t = idx / Wo;
+    const int oh = t % Ho; t /= Ho;
+    const int od = t % Do;
+    const long nc = t / Do;
+    int d0, d1, h0, h1, w0, w1;
+    float ld0, ld1, lh0, lh1, lw0, lw1;
+    lin_src(od, rs, Di, d0, d1, ld0, ld1);
+    lin_src(oh, rs, Hi, h0, h1, lh0, lh1);
+    lin_src(ow, rs, Wi, w0, w1, lw0, lw1);
+    const float* p = x + nc * Di * Hi * Wi;
+#define XV(d, h, w) p[((long)(d) * Hi + (h)) * Wi + (w)]
+    const float v = ld0 * (lh0 * (lw0 * XV(d0, h0, w0) + lw1 * XV(d0, h0, w1)) +
+                           lh1 * (lw0 * XV(d0, h1, w0) + lw1 * XV(d0, h1, w1))) +
+                    ld1 * (lh0 * (lw0 * XV(d1, h0, w0) + lw1 * XV(d1, h0, w1)) +
+                           lh1 * (lw0 * XV(d1, h1, w0) + lw1 * XV(d1, h1, w1)));
+#undef XV
+    y[idx] = v;
+  }
+}
+
+// weight with which output o contributes to input i along one dim (0 if none)
+__device__ __forceinline__ float lin_w(int o, int i, float rs, int n) {
+  int i0, i1;
+  float l0, l1;
+  lin_src(o, rs, n, i0, i1, l0, l1);
+  return (i0 == i ? l0 : 0.f) + (i1 == i ? l1 : 0.f);
+}
+
+// gather form of the trilinear backward: input i collects outputs o in [s*i - ceil(s/2), s*i + 3s/2 - 1]
+// (even s exact; odd s a superset -- weights are match-tested per candidate, so a superset is safe).
+__global__ void trilinear_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, long NC, int Di, int Hi,
+                                     int Wi, int s) {
+  const int Do = Di * s, Ho = Hi * s, Wo = Wi * s;
+  const float rs = 1.0f / (float)s;
+  const long total = NC * Di * Hi * Wi;
+  const int lo_off = (s + 1) / 2, hi_off = (3 * s) / 2 - 1 + (s & 1);
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int w = idx % Wi;
+    long t = idx / Wi;
+    const int h = t % Hi; t /= Hi;
+    const int d = t % Di;
+    const long nc = t / Di;
+    const float* p = gy + nc * Do * Ho * Wo;
+    const int od0 = max(0, s * d - lo_off), od1 = min(Do - 1, s * d + hi_off);
+    const int oh0 = max(0, s * h - lo_off), oh1 = min(Ho - 1, s * h + hi_off);
+    const int ow0 = max(0, s * w - lo_off), ow1 = min(Wo - 1, s * w + hi_off);
+    float acc = 0.f;
+    for (int od = od0; od <= od1; ++od) {
+      const float wd = lin_w(od, d, rs, Di);
+      if (wd == 0.f) continue;
+      for (int oh = oh0; oh <= oh1; ++oh) {
+        const float wh = lin_w(oh, h, rs, Hi);
+        if (wh == 0.f) continue;
+        const float* row = p + ((long)od * Ho + oh) * Wo;
+        float r = 0.f;
+        for (int ow = ow0; ow <= ow1; ++ow) r += lin_w(ow, w, rs, Wi) * row[ow];
+        acc += wd * wh * r;
+      }
+    }
+    gx[idx] = acc;
+  }
+}
+
+static int ew_grid(long total) {
+  long g = (total + 255) / 256;
+  return (int)(g < 8192 ? (g > 0 ? g : 1) : 8192);
+}
+
+static void chunking(long S, int C, int* nchunk, long* chunk_len) {
+  // enough blocks to fill 256 CUs a few times over, chunks a multiple of 1024 floats
+  long want = (2048 + C - 1) / C;
+  long len = (S + want - 1) / want;
+  len = ((len + 1023) / 1024) * 1024;
+  *chunk_len = len;
+  *nchunk = (int)((S + len - 1) / len);
+}
+
+extern "C" int dca_bn_num_chunks(int C, long S) {
+  int n; long l;
+  chunking(S, C, &n, &l);
+  return n;
+}
+
+extern "C" int dca_bn_stats(const float* x, double* part, int N, int C, long S, hipStream_t stream) {
+  DCA_REQUIRE(x && part && N > 0 && C > 0 && S > 0 && C <= 65535);
+  int nchunk; long len;
+  chunking(S, C, &nchunk, &len);
+  const int vec = (S % 4 == 0) && (((uintptr_t)x & 15) == 0);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(C, nchunk), dim3(256), 0, stream, x, part, N, C, S, nchunk, len, vec);
+  return dca_launch_status();
+}
+
+extern "C" int dca_bn_finalize(const double* part, int nchunk, double count, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, float momentum, float eps, int training,
+                               float* stats, int C, hipStream_t stream) {
+  DCA_REQUIRE(stats && C > 0 && (training ? (part != nullptr && nchunk > 0) : (running_mean && running_var)));
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, part, nchunk, count, gamma, beta,
+                     running_mean, running_var, momentum, eps, training, stats, C);
+  return dca_launch_status();
+}
+
+extern "C" int dca_bn_apply(const float* y, const float* stats, const float* res_pre, const float* res_post, float* z,
+                            int N, int C, long S, float slope, hipStream_t stream) {
+  DCA_REQUIRE(y && stats && z && N > 0 && C > 0 && S > 0);
+  const long total = (long)N * C * S;
+  const uintptr_t al = (uintptr_t)y | (uintptr_t)z | (uintptr_t)res_pre | (uintptr_t)res_post;
+  const int vec = (S % 4 == 0) && ((al & 15) == 0);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(vec ? total / 4 : total)), dim3(256), 0, stream, y, stats, res_pre,
+                     res_post, z, C, S, total, slope, vec);
+  return dca_launch_status();
+}
+
+extern "C" int dca_bn_backward(const float* dz, const float* y, const float* res_pre, const float* stats,
+                               double* part, float* dgb, float* dy, float* g_out, int N, int C, long S, float slope,
+                               int training, hipStream_t stream) {
+  DCA_REQUIRE(dz && y && stats && part && dgb && dy && N > 0 && C > 0 && S > 0 && C <= 65535);
+  int nchunk; long len;
+  chunking(S, C, &nchunk, &len);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, nchunk), dim3(256), 0, stream, dz, y, res_pre, stats, part, N, C, S,
+                     nchunk, len, slope);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, part, nchunk,
+                     (double)N * (double)S, dgb, C);
+  const long total = (long)N * C * S;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, dz, y, res_pre, stats, dgb, dy,
+                     g_out, C, S, total, slope, training);
+  return dca_launch_status();
+}
+
+extern "C" int dca_avgpool3d_fwd(const float* x, float* y, long NC, int Di, int Hi, int Wi, hipStream_t stream) {
+  DCA_REQUIRE(x && y && NC > 0 && Di > 0 && Hi > 0 && Wi > 0);
+  const int Do = (Di + 1) / 2, Ho = (Hi + 1) / 2, Wo = (Wi + 1) / 2;  // floor((i+2-3)/2)+1
+  hipLaunchKernelGGL(avgpool3d_fwd_kernel, dim3(ew_grid(NC * Do * Ho * Wo)), dim3(256), 0, stream, x, y, NC, Di, Hi,
+                     Wi, Do, Ho, Wo);
+  return dca_launch_status();
+}
+
+extern "C" int dca_avgpool3d_bwd(const float* gy, float* gx, long NC, int Di, int Hi, int Wi, hipStream_t stream) {
+  DCA_REQUIRE(gy && gx && NC > 0 && Di > 0 && Hi > 0 && Wi > 0);
+  const int Do = (Di + 1) / 2, Ho = (Hi + 1) / 2, Wo = (Wi + 1) / 2;
+  hipLaunchKernelGGL(avgpool3d_bwd_kernel, dim3(ew_grid(NC * Di * Hi * Wi)), dim3(256), 0, stream, gy, gx, NC, Di, Hi,
+                     Wi, Do, Ho, Wo);
+  return dca_launch_status();
+}
+
+extern "C" int dca_trilinear_fwd(const float* x, float* y, long NC, int Di, int Hi, int Wi, int scale,
+                                 hipStream_t stream) {
+  DCA_REQUIRE(x && y && NC > 0 && Di > 0 && Hi > 0 && Wi > 0 && scale >= 1);
+  const long total = NC * Di * Hi * Wi * scale * scale * scale;
+  hipLaunchKernelGGL(trilinear_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, x, y, NC, Di, Hi, Wi, scale);
+  return dca_launch_status();
+}
+
+extern "C" int dca_trilinear_bwd(const float* gy, float* gx, long NC, int Di, int Hi, int Wi, int scale,
+                                 hipStream_t stream) {
+  DCA_REQUIRE(gy && gx && NC > 0 && Di > 0 && Hi > 0 && Wi > 0 && scale >= 1);
+  hipLaunchKernelGGL(trilinear_bwd_kernel, dim3(ew_grid(NC * Di * Hi * Wi)), dim3(256), 0, stream, gy, gx, NC, Di, Hi,
+                     Wi, scale);
+  return dca_launch_status();
+}

@@ -1,0 +1,88 @@
+"""Mirror of the reference's models/augment/cva.py (Multi_Aggregation, cva) on HIP kernels."""
+import torch.nn as nn
+
+from .._bootstrap import ensure as _ensure
+from ..submodule import ConvBn3d, ConvBnReLU3d, conv3d_plain, convbn_3d
+from .semantic_level import SemanticLevelContext
+
+ops = _ensure().ops
+
+
+class _DeconvBn3d(nn.Sequential):
+    """Sequential(ConvTranspose3d(k3, s2, p1, op1, bias=False), BatchNorm3d) -- keys '0.weight', '1.*'."""
+
+    def __init__(self, cin, cout):
+        super().__init__(nn.ConvTranspose3d(cin, cout, 3, padding=1, output_padding=1, stride=2, bias=False),
+                         nn.BatchNorm3d(cout))
+
+    def forward(self, x, slope=1.0, res_pre=None, res_post=None):
+        return ops.convbn3d(x, self[0], self[1], slope, res_pre, res_post)
+
+
+class Multi_Aggregation(nn.Module):
+    """reference cva.py:13-31: conv s2 -> conv -> deconv s2, 1x1x1 skip, ReLU(sum)."""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        self.conv1 = ConvBnReLU3d(in_channels, in_channels * 2, 3, 2, 1)
+        self.conv2 = ConvBnReLU3d(in_channels * 2, in_channels * 2, 3, 1, 1)
+        self.conv3 = _DeconvBn3d(in_channels * 2, in_channels)
+        self.redir = convbn_3d(in_channels, in_channels, kernel_size=1, stride=1, pad=0)
+
+    def forward(self, x, res_post=None):
+        c2 = self.conv2(self.conv1(x))
+        skip = self.redir(x)
+        # relu(conv3(c2) + redir(x)) [+ res_post, fused: the caller's `cost0 + augmented_cost`]
+        return self.conv3(c2, slope=0.0, res_pre=skip, res_post=res_post)
+
+
+class _Downsample(nn.Sequential):
+    """Sequential(AvgPool3d(3,2,1), convbn_3d(32,32,3,1,1), ReLU) -- keys '1.0.weight', '1.1.*'."""
+
+    def __init__(self):
+        super().__init__(nn.AvgPool3d((3, 3, 3), stride=2, padding=1), ConvBn3d(32, 32, 3, 1, 1),
+                         nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        return self[1](ops.avg_pool3d_k3s2p1(x), slope=0.0)
+
+
+class _Classify(nn.Sequential):
+    """Sequential(convbn_3d, ReLU, Conv3d(C,1,3,p1)) -- keys '0.0.weight', '0.1.*', '2.weight'."""
+
+    def __init__(self, c):
+        super().__init__(ConvBn3d(c, c, 3, 1, 1), nn.ReLU(inplace=True),
+                         nn.Conv3d(c, 1, kernel_size=3, padding=1, stride=1, bias=False))
+
+    def forward(self, x):
+        return conv3d_plain(self[0](x, slope=0.0), self[2])
+
+
+class cva(nn.Module):
+    """reference cva.py:33-72.  forward(cost_volume) -> (prob_volume.unsqueeze(1), augmented_cost)."""
+
+    def __init__(self, max_disp, in_channel, downsample=True):
+        super().__init__()
+        self.max_disp = max_disp
+        self.channel = in_channel
+        if downsample:
+            self.downsample = _Downsample()
+        self.slc_net = SemanticLevelContext(feats_channels=self.channel, transform_channels=self.channel,
+                                            concat_input=True)
+        self.classify = _Classify(self.channel)
+        self.fuse = nn.Sequential(ConvBn3d(64, 32, 1, 1, 0))
+        self.cost_agg = Multi_Aggregation(self.channel)
+
+    def forward(self, cost_volume, downsample=True, res_post=None):
+        if downsample:
+            cost_down = self.downsample(cost_volume)
+            prob_volume = self.classify(cost_down).squeeze(1)
+            aug_down = self.slc_net(cost_down, prob_volume)
+            aug = ops.trilinear_upsample(aug_down, 2)
+        else:
+            prob_volume = self.classify(cost_volume).squeeze(1)
+            aug = self.slc_net(cost_volume, prob_volume)
+        # fuse(cat([aug, cost_volume], 1)) without materialising the 64-channel concat
+        aug = self.fuse[0](aug, x2=cost_volume)
+        aug = self.cost_agg(aug, res_post=res_post)
+        return prob_volume.unsqueeze(1), aug

@@ -1,0 +1,536 @@
+"""Autograd operators of the DCANet hot path, each a thin host wrapper over the C ABI of
+libdca_hip.so (include/dca_hip.h).  PyTorch is used for device memory, streams and autograd graph
+bookkeeping only; every arithmetic step on the path runs in a hand-written HIP kernel.
+
+There is no CPU / eager fallback: tensors must be fp32 on a ROCm device and the library must load.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+_vp = ctypes.c_void_p
+
+
+def _L():
+    return _lib.load()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return _vp(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(rc: int, name: str):
+    if rc != 0:
+        raise RuntimeError(f"{name} failed with hipError_t {rc}")
+
+
+def _req(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(
+            f"{name}: the DCANet hot path runs only as HIP kernels on a ROCm device (got "
+            f"{'a ' + str(t.device) + ' tensor' if isinstance(t, torch.Tensor) else type(t)}); there is no CPU fallback")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name}: expected float32, got {t.dtype}")
+    t = t.contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone(memory_format=torch.contiguous_format)
+    return t
+
+
+def _opt(t, name):
+    return None if t is None else _req(t, name)
+
+
+# ------------------------------------------------------------------------------------------------
+# cost volumes
+# ------------------------------------------------------------------------------------------------
+class _GwcVolume(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ref, tgt, maxdisp, num_groups):
+        ref, tgt = _req(ref, "build_gwc_volume"), _req(tgt, "build_gwc_volume")
+        B, C, H, W = ref.shape
+        vol = torch.empty((B, num_groups, maxdisp, H, W), device=ref.device, dtype=torch.float32)
+        with torch.cuda.device_of(ref):
+            _chk(_L().dca_gwc_volume_fwd(_ptr(ref), _ptr(tgt), _ptr(vol), B, C, H, W, maxdisp, num_groups, _stream()),
+                 "dca_gwc_volume_fwd")
+        ctx.save_for_backward(ref, tgt)
+        ctx.meta = (maxdisp, num_groups)
+        return vol
+
+    @staticmethod
+    def backward(ctx, gvol):
+        ref, tgt = ctx.saved_tensors
+        maxdisp, G = ctx.meta
+        gvol = _req(gvol, "build_gwc_volume.backward")
+        B, C, H, W = ref.shape
+        gref, gtgt = torch.empty_like(ref), torch.empty_like(tgt)
+        with torch.cuda.device_of(ref):
+            _chk(_L().dca_gwc_volume_bwd(_ptr(gvol), _ptr(ref), _ptr(tgt), _ptr(gref), _ptr(gtgt), B, C, H, W,
+                                         maxdisp, G, _stream()), "dca_gwc_volume_bwd")
+        return gref, gtgt, None, None
+
+
+class _ConcatVolume(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ref, tgt, maxdisp):
+        ref, tgt = _req(ref, "build_concat_volume"), _req(tgt, "build_concat_volume")
+        B, C, H, W = ref.shape
+        vol = torch.empty((B, 2 * C, maxdisp, H, W), device=ref.device, dtype=torch.float32)
+        with torch.cuda.device_of(ref):
+            _chk(_L().dca_concat_volume_fwd(_ptr(ref), _ptr(tgt), _ptr(vol), B, C, H, W, maxdisp, _stream()),
+                 "dca_concat_volume_fwd")
+        ctx.meta = (B, C, H, W, maxdisp)
+        return vol
+
+    @staticmethod
+    def backward(ctx, gvol):
+        B, C, H, W, maxdisp = ctx.meta
+        gvol = _req(gvol, "build_concat_volume.backward")
+        gref = torch.empty((B, C, H, W), device=gvol.device, dtype=torch.float32)
+        gtgt = torch.empty_like(gref)
+        with torch.cuda.device_of(gvol):
+            _chk(_L().dca_concat_volume_bwd(_ptr(gvol), _ptr(gref), _ptr(gtgt), B, C, H, W, maxdisp, _stream()),
+                 "dca_concat_volume_bwd")
+        return gref, gtgt, None
+
+
+def gwc_volume(ref, tgt, maxdisp, num_groups):
+    return _GwcVolume.apply(ref, tgt, int(maxdisp), int(num_groups))
+
+
+def concat_volume(ref, tgt, maxdisp):
+    return _ConcatVolume.apply(ref, tgt, int(maxdisp))
+
+
+# ------------------------------------------------------------------------------------------------
+# softmax(dim=1) / soft-argmin / disparity regression on (B, K, *spatial)
+# ------------------------------------------------------------------------------------------------
+class _SoftArgmin(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mode):
+        x = _req(x, "softargmin")
+        B, K = x.shape[0], x.shape[1]
+        HW = x[0, 0].numel()
+        out = torch.empty_like(x) if mode == 0 else torch.empty((B, 1) + tuple(x.shape[2:]), device=x.device,
+                                                                dtype=torch.float32)
+        with torch.cuda.device_of(x):
+            _chk(_L().dca_softargmin_fwd(_ptr(x), _ptr(out), B, K, HW, mode, _stream()), "dca_softargmin_fwd")
+        ctx.mode = mode
+        ctx.save_for_backward(out if mode == 0 else x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (aux,) = ctx.saved_tensors
+        g = _req(g, "softargmin.backward")
+        B, K = aux.shape[0], aux.shape[1]
+        HW = aux[0, 0].numel()
+        gx = torch.empty_like(aux)
+        with torch.cuda.device_of(aux):
+            _chk(_L().dca_softargmin_bwd(_ptr(aux), _ptr(g), _ptr(gx), B, K, HW, ctx.mode, _stream()),
+                 "dca_softargmin_bwd")
+        return gx, None
+
+
+def softmax_dim1(x):
+    return _SoftArgmin.apply(x, 0)
+
+
+def softargmin(x):
+    """disparity_regression(softmax(x, 1), K) fused: (B,K,...) logits -> (B,1,...)."""
+    return _SoftArgmin.apply(x, 1)
+
+
+def regression(x):
+    """disparity_regression(x, K) for an arbitrary x: sum_k k*x[:,k], keepdim."""
+    return _SoftArgmin.apply(x, 2)
+
+
+# ------------------------------------------------------------------------------------------------
+# 3D convolutions
+# ------------------------------------------------------------------------------------------------
+def _round_up(a, m):
+    return (a + m - 1) // m * m
+
+
+def _prep_weight(w2d_src, A, B, K, src_ab, flip, ksize, stride, transposed):
+    """wt[tap][Apad][Bpad] for dca_conv3d_forward (padding rules of include/dca_hip.h)."""
+    if ksize == 1:
+        Apad = 32 if A <= 32 else 64
+        Bpad = 32
+    else:
+        Apad = _round_up(A, 8)
+        Bpad = 32 if (transposed or (stride == 1 and B <= 32)) else 64
+    wt = torch.empty((K, Apad, Bpad), device=w2d_src.device, dtype=torch.float32)
+    _chk(_L().dca_conv3d_prep_weight(_ptr(w2d_src), _ptr(wt), A, B, Apad, Bpad, K, int(src_ab), int(flip), _stream()),
+         "dca_conv3d_prep_weight")
+    return wt, Apad
+
+
+def _out_dims(dims, ksize, stride, transposed):
+    if ksize == 1 or stride == 1:
+        return tuple(dims)
+    if transposed:
+        return tuple(2 * d for d in dims)
+    return tuple((d + 1) // 2 for d in dims)
+
+
+def _conv_launch(x, x2, wt, CinPad, Cin, C1, Cout, ksize, stride, transposed, scale=None, shift=None, slope=1.0,
+                 res_pre=None, res_post=None):
+    N = x.shape[0]
+    Di, Hi, Wi = x.shape[2:]
+    Do, Ho, Wo = _out_dims((Di, Hi, Wi), ksize, stride, transposed)
+    y = torch.empty((N, Cout, Do, Ho, Wo), device=x.device, dtype=torch.float32)
+    _chk(_L().dca_conv3d_forward(_ptr(x), _ptr(x2), _ptr(wt), _ptr(y), _ptr(scale), _ptr(shift), _ptr(res_pre),
+                                 _ptr(res_post), float(slope), N, Cin, C1, Cout, CinPad, Di, Hi, Wi, Do, Ho, Wo,
+                                 ksize, stride, int(transposed), _stream()), "dca_conv3d_forward")
+    return y
+
+
+def _conv_forward_impl(x, x2, weight, stride, transposed, scale=None, shift=None, slope=1.0, res_pre=None,
+                       res_post=None):
+    ksize = weight.shape[2]
+    K = ksize ** 3
+    if transposed:
+        Cin, Cout = weight.shape[0], weight.shape[1]
+        wt, CinPad = _prep_weight(weight, Cin, Cout, K, 1, 0, ksize, stride, True)
+    else:
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        wt, CinPad = _prep_weight(weight, Cin, Cout, K, 0, 0, ksize, stride, False)
+    C1 = x.shape[1]
+    assert C1 + (x2.shape[1] if x2 is not None else 0) == Cin, "conv3d: channel mismatch"
+    return _conv_launch(x, x2, wt, CinPad, Cin, C1, Cout, ksize, stride, transposed, scale, shift, slope, res_pre,
+                        res_post)
+
+
+def _wgrad(x, dy, dw_view_ptr_tensor, dst_offset, Cx, Cy, ksize, stride, s_cy, s_cx):
+    """dw[cy*s_cy + cx*s_cx + k] (+dst_offset floats) = sum dy[cy] * x[cx] (see dca_hip.h)."""
+    N = x.shape[0]
+    Di, Hi, Wi = x.shape[2:]
+    Do, Ho, Wo = dy.shape[2:]
+    nws = _L().dca_conv3d_wgrad_workspace(N, Cx, Cy, Do, Ho, Wo, ksize, stride)
+    part = torch.empty((nws,), device=x.device, dtype=torch.float32)
+    dst = _vp(dw_view_ptr_tensor.data_ptr() + 4 * dst_offset)
+    _chk(_L().dca_conv3d_wgrad(_ptr(x), _ptr(dy), _ptr(part), dst, N, Cx, Cy, Di, Hi, Wi, Do, Ho, Wo, ksize, stride,
+                               s_cy, s_cx, _stream()), "dca_conv3d_wgrad")
+
+
+class _Conv3d(torch.autograd.Function):
+    """Conv3d (k=3 pad=1 stride 1|2, or k=1) / ConvTranspose3d (k=3 s=2 p=1 op=1), bias=False.
+    Optional second input x2 = implicit channel concat for the 1x1x1 `fuse` conv."""
+
+    @staticmethod
+    def forward(ctx, x, x2, weight, stride, transposed):
+        x, weight = _req(x, "conv3d"), _req(weight, "conv3d.weight")
+        x2 = _opt(x2, "conv3d.x2")
+        with torch.cuda.device_of(x):
+            y = _conv_forward_impl(x, x2, weight, stride, transposed)
+        ctx.save_for_backward(x, x2, weight)
+        ctx.meta = (stride, transposed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, x2, weight = ctx.saved_tensors
+        stride, transposed = ctx.meta
+        dy = _req(dy, "conv3d.backward")
+        ksize = weight.shape[2]
+        K = ksize ** 3
+        gx = gx2 = gw = None
+        need_x, need_x2, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        with torch.cuda.device_of(x):
+            if transposed:
+                Cin, Cout = weight.shape[0], weight.shape[1]
+                if need_x:  # stride-2 conv of dy with Wt read as a Conv3d weight [Cin][Cout][K]
+                    wt, CinPad = _prep_weight(weight, Cout, Cin, K, 0, 0, 3, 2, False)
+                    gx = _conv_launch(dy, None, wt, CinPad, Cout, Cout, Cin, 3, 2, False)
+                if need_w:
+                    gw = torch.empty_like(weight)
+                    _wgrad(dy, x, gw, 0, Cout, Cin, 3, 2, Cout * K, K)
+            elif ksize == 3:
+                Cout, Cin = weight.shape[0], weight.shape[1]
+                if need_x:
+                    if stride == 1:
+                        wt, CinPad = _prep_weight(weight, Cout, Cin, K, 1, 1, 3, 1, False)
+                        gx = _conv_launch(dy, None, wt, CinPad, Cout, Cout, Cin, 3, 1, False)
+                    else:
+                        wt, CinPad = _prep_weight(weight, Cout, Cin, K, 1, 0, 3, 2, True)
+                        gx = _conv_launch(dy, None, wt, CinPad, Cout, Cout, Cin, 3, 2, True)
+                        if gx.shape != x.shape:
+                            raise RuntimeError("stride-2 conv backward needs even input dims")
+                if need_w:
+                    gw = torch.empty_like(weight)
+                    _wgrad(x, dy, gw, 0, Cin, Cout, 3, stride, Cin * K, K)
+            else:
+                Cout, Cin = weight.shape[0], weight.shape[1]
+                w2 = weight.reshape(Cout, Cin)
+                C1 = x.shape[1]
+                if need_x:
+                    halves = []
+                    for c0 in range(0, C1, 32):   # the 1x1 kernel produces <= 32 output channels per launch
+                        wa = w2[:, c0:min(C1, c0 + 32)].contiguous()
+                        wt, CinPad = _prep_weight(wa, Cout, wa.shape[1], 1, 1, 0, 1, 1, False)
+                        halves.append(_conv_launch(dy, None, wt, CinPad, Cout, Cout, wa.shape[1], 1, 1, False))
+                    gx = halves[0] if len(halves) == 1 else torch.cat(halves, 1)
+                if x2 is not None and need_x2:
+                    wb = w2[:, C1:].contiguous()
+                    wt, CinPad = _prep_weight(wb, Cout, Cin - C1, 1, 1, 0, 1, 1, False)
+                    gx2 = _conv_launch(dy, None, wt, CinPad, Cout, Cout, Cin - C1, 1, 1, False)
+                if need_w:
+                    gw = torch.empty_like(weight)
+                    _wgrad(x, dy, gw, 0, C1, Cout, 1, 1, Cin, 1)
+                    if x2 is not None:
+                        _wgrad(x2, dy, gw, C1, Cin - C1, Cout, 1, 1, Cin, 1)
+        return gx, gx2, gw, None, None
+
+
+def conv3d(x, weight, stride=1, transposed=False, x2=None):
+    return _Conv3d.apply(x, x2, weight, int(stride), bool(transposed))
+
+
+def conv3d_fused_inference(x, weight, stride, transposed, scale, shift, slope, res_pre=None, res_post=None, x2=None):
+    """Forward-only conv with the affine (folded BatchNorm) + activation + residual epilogue fused."""
+    x, weight = _req(x, "conv3d"), _req(weight, "conv3d.weight")
+    with torch.cuda.device_of(x):
+        return _conv_forward_impl(x, _opt(x2, "x2"), weight, int(stride), bool(transposed), _opt(scale, "scale"),
+                                  _opt(shift, "shift"), slope, _opt(res_pre, "res_pre"), _opt(res_post, "res_post"))
+
+
+# ------------------------------------------------------------------------------------------------
+# BatchNorm3d + activation + residual
+# ------------------------------------------------------------------------------------------------
+def bn_stats_vector(y, gamma, beta, running_mean, running_var, training, momentum, eps):
+    """[mean | invstd | scale | shift] (4*C floats); updates the running stats in place when training."""
+    N, C = y.shape[0], y.shape[1]
+    S = y[0, 0].numel()
+    stats = torch.empty((4 * C,), device=y.device, dtype=torch.float32)
+    lib = _L()
+    if training:
+        nchunk = lib.dca_bn_num_chunks(C, S)
+        part = torch.empty((C * nchunk * 2,), device=y.device, dtype=torch.float64)
+        _chk(lib.dca_bn_stats(_ptr(y), _ptr(part), N, C, S, _stream()), "dca_bn_stats")
+        _chk(lib.dca_bn_finalize(_ptr(part), nchunk, float(N * S), _ptr(gamma), _ptr(beta), _ptr(running_mean),
+                                 _ptr(running_var), float(momentum), float(eps), 1, _ptr(stats), C, _stream()),
+             "dca_bn_finalize")
+    else:
+        _chk(lib.dca_bn_finalize(None, 0, float(N * S), _ptr(gamma), _ptr(beta), _ptr(running_mean),
+                                 _ptr(running_var), float(momentum), float(eps), 0, _ptr(stats), C, _stream()),
+             "dca_bn_finalize")
+    return stats
+
+
+def bn_eval_affine(bn):
+    """[mean | invstd | scale | shift] of an eval-mode BatchNorm (running statistics), 4*C floats."""
+    C = bn.num_features
+    stats = torch.empty((4 * C,), device=bn.running_mean.device, dtype=torch.float32)
+    _chk(_L().dca_bn_finalize(None, 0, 1.0, _ptr(bn.weight), _ptr(bn.bias), _ptr(bn.running_mean),
+                              _ptr(bn.running_var), 0.1, float(bn.eps), 0, _ptr(stats), C, _stream()),
+         "dca_bn_finalize")
+    return stats
+
+
+class _BnAct(torch.autograd.Function):
+    """z = act(BN(y) + res_pre) + res_post with nn.BatchNorm3d semantics."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, training, momentum, eps, slope, res_pre, res_post):
+        y = _req(y, "batch_norm")
+        res_pre, res_post = _opt(res_pre, "res_pre"), _opt(res_post, "res_post")
+        N, C = y.shape[0], y.shape[1]
+        S = y[0, 0].numel()
+        with torch.cuda.device_of(y):
+            stats = bn_stats_vector(y, gamma, beta, running_mean, running_var, training, momentum, eps)
+            z = torch.empty_like(y)
+            _chk(_L().dca_bn_apply(_ptr(y), _ptr(stats), _ptr(res_pre), _ptr(res_post), _ptr(z), N, C, S, float(slope),
+                                   _stream()), "dca_bn_apply")
+        ctx.save_for_backward(y, stats, res_pre if slope != 1.0 else None)
+        ctx.meta = (training, slope, res_pre is not None, res_post is not None)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        y, stats, res_pre = ctx.saved_tensors
+        training, slope, has_pre, has_post = ctx.meta
+        dz = _req(dz, "batch_norm.backward")
+        N, C = y.shape[0], y.shape[1]
+        S = y[0, 0].numel()
+        lib = _L()
+        with torch.cuda.device_of(y):
+            nchunk = lib.dca_bn_num_chunks(C, S)
+            part = torch.empty((C * nchunk * 2,), device=y.device, dtype=torch.float64)
+            dgb = torch.empty((4 * C,), device=y.device, dtype=torch.float32)
+            dy = torch.empty_like(y)
+            want_g = has_pre and slope != 1.0 and ctx.needs_input_grad[9]
+            g_out = torch.empty_like(y) if want_g else None
+            _chk(lib.dca_bn_backward(_ptr(dz), _ptr(y), _ptr(res_pre), _ptr(stats), _ptr(part), _ptr(dgb), _ptr(dy),
+                                     _ptr(g_out), N, C, S, float(slope), int(training), _stream()), "dca_bn_backward")
+        g_pre = None
+        if has_pre and ctx.needs_input_grad[9]:
+            g_pre = g_out if want_g else dz
+        g_post = dz if (has_post and ctx.needs_input_grad[10]) else None
+        return dy, dgb[:C], dgb[C:2 * C], None, None, None, None, None, None, g_pre, g_post
+
+
+def bn_act(y, bn, slope=1.0, res_pre=None, res_post=None):
+    """Applies the nn.BatchNorm3d module `bn` (parameters/buffers only; its forward is never called)."""
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    training = bn.training or bn.running_mean is None
+    z = _BnAct.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, float(slope),
+                     res_pre, res_post)
+    if bn.training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return z
+
+
+def convbn3d(x, conv, bn, slope=1.0, res_pre=None, res_post=None, x2=None):
+    """`convbn_3d` (models/submodule.py:121-124) + activation + residual adds, on the HIP kernels.
+
+    conv: nn.Conv3d / nn.ConvTranspose3d (bias=False), bn: nn.BatchNorm3d -- used as parameter holders.
+    Inference (eval BN, no grad): one fused launch (BN folded into the conv epilogue).  Otherwise conv ->
+    batch statistics -> apply, each with a HIP backward."""
+    transposed = isinstance(conv, torch.nn.ConvTranspose3d)
+    stride = conv.stride[0]
+    if not bn.training and not torch.is_grad_enabled():
+        xx = _req(x, "convbn3d")
+        with torch.cuda.device_of(xx):
+            stats = bn_eval_affine(bn)
+        C = bn.num_features
+        return conv3d_fused_inference(xx, conv.weight, stride, transposed, stats[2 * C:3 * C], stats[3 * C:], slope,
+                                      res_pre, res_post, x2)
+    y = conv3d(x, conv.weight, stride, transposed, x2)
+    return bn_act(y, bn, slope, res_pre, res_post)
+
+
+# ------------------------------------------------------------------------------------------------
+# pooling / interpolation
+# ------------------------------------------------------------------------------------------------
+class _AvgPool3d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _req(x, "avg_pool3d")
+        N, C, D, H, W = x.shape
+        y = torch.empty((N, C, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2), device=x.device, dtype=torch.float32)
+        with torch.cuda.device_of(x):
+            _chk(_L().dca_avgpool3d_fwd(_ptr(x), _ptr(y), N * C, D, H, W, _stream()), "dca_avgpool3d_fwd")
+        ctx.shape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = _req(gy, "avg_pool3d.backward")
+        N, C, D, H, W = ctx.shape
+        gx = torch.empty(ctx.shape, device=gy.device, dtype=torch.float32)
+        with torch.cuda.device_of(gy):
+            _chk(_L().dca_avgpool3d_bwd(_ptr(gy), _ptr(gx), N * C, D, H, W, _stream()), "dca_avgpool3d_bwd")
+        return gx
+
+
+class _Trilinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        x = _req(x, "interpolate")
+        N, C, D, H, W = x.shape
+        y = torch.empty((N, C, D * scale, H * scale, W * scale), device=x.device, dtype=torch.float32)
+        with torch.cuda.device_of(x):
+            _chk(_L().dca_trilinear_fwd(_ptr(x), _ptr(y), N * C, D, H, W, scale, _stream()), "dca_trilinear_fwd")
+        ctx.meta = (tuple(x.shape), scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        shape, scale = ctx.meta
+        gy = _req(gy, "interpolate.backward")
+        N, C, D, H, W = shape
+        gx = torch.empty(shape, device=gy.device, dtype=torch.float32)
+        with torch.cuda.device_of(gy):
+            _chk(_L().dca_trilinear_bwd(_ptr(gy), _ptr(gx), N * C, D, H, W, scale, _stream()), "dca_trilinear_bwd")
+        return gx, None
+
+
+def avg_pool3d_k3s2p1(x):
+    return _AvgPool3d.apply(x)
+
+
+def trilinear_upsample(x, scale):
+    return _Trilinear.apply(x, int(scale))
+
+
+# ------------------------------------------------------------------------------------------------
+# DCA: context injection and disparity attention
+# ------------------------------------------------------------------------------------------------
+class _ContextInject(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, preds):
+        x, preds = _req(x, "context_inject"), _req(preds, "context_inject.preds")
+        B, C, n = x.shape[:3]
+        HW = x.shape[3] * x.shape[4]
+        key = torch.empty_like(x)
+        kstar = torch.empty((B, HW), device=x.device, dtype=torch.int32)
+        e = torch.empty((B, HW), device=x.device, dtype=torch.float32)
+        pm = torch.empty_like(e)
+        denom = torch.empty((B, n), device=x.device, dtype=torch.float32)
+        with torch.cuda.device_of(x):
+            _chk(_L().dca_context_inject_fwd(_ptr(x), _ptr(preds), _ptr(key), _ptr(kstar), _ptr(e), _ptr(pm),
+                                             _ptr(denom), B, C, n, HW, _stream()), "dca_context_inject_fwd")
+        ctx.save_for_backward(x, preds, kstar, e, pm, denom)
+        ctx.mark_non_differentiable(kstar)
+        return key, kstar
+
+    @staticmethod
+    def backward(ctx, dkey, _unused):
+        x, preds, kstar, e, pm, denom = ctx.saved_tensors
+        dkey = _req(dkey, "context_inject.backward")
+        B, C, n = x.shape[:3]
+        HW = x.shape[3] * x.shape[4]
+        dx, dpreds = torch.empty_like(x), torch.empty_like(preds)
+        dw = torch.empty_like(e)
+        T = torch.empty_like(denom)
+        with torch.cuda.device_of(x):
+            _chk(_L().dca_context_inject_bwd(_ptr(dkey), _ptr(x), _ptr(preds), _ptr(kstar), _ptr(e), _ptr(pm),
+                                             _ptr(denom), _ptr(dx), _ptr(dpreds), _ptr(dw), _ptr(T), B, C, n, HW,
+                                             _stream()), "dca_context_inject_bwd")
+        return dx, dpreds
+
+
+class _DispAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v):
+        q, k, v = _req(q, "attention.q"), _req(k, "attention.k"), _req(v, "attention.v")
+        B, C, n = q.shape[:3]
+        HW = q.shape[3] * q.shape[4]
+        out = torch.empty_like(q)
+        with torch.cuda.device_of(q):
+            _chk(_L().dca_disp_attention_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, C, n, HW, _stream()),
+                 "dca_disp_attention_fwd")
+        ctx.save_for_backward(q, k, v)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v = ctx.saved_tensors
+        dout = _req(dout, "attention.backward")
+        B, C, n = q.shape[:3]
+        HW = q.shape[3] * q.shape[4]
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        with torch.cuda.device_of(q):
+            _chk(_L().dca_disp_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(dout), _ptr(dq), _ptr(dk), _ptr(dv), B,
+                                             C, n, HW, _stream()), "dca_disp_attention_bwd")
+        return dq, dk, dv
+
+
+def context_inject(x, preds):
+    """SemanticLevelContext's feats_sl + inputs (semantic_level.py:96-126); returns (key_feats, kstar)."""
+    return _ContextInject.apply(x, preds)
+
+
+def disparity_attention(q, k, v):
+    return _DispAttention.apply(q, k, v)

@@ -1,0 +1,130 @@
+/* C ABI of libdca_hip.so -- the MI355X (gfx950) kernels behind the DCANet cost-volume hot path.
+ *
+ * The reference (cocowy1/Cost-Volume-Aggregation-in-Stereo-Matching-Revisited) has no FFI of its own
+ * on this path: every step is a PyTorch op called from Python.  The boundary a maintainer binds is
+ * therefore "one extern-C launcher per op the Python path calls", taking raw device pointers,
+ * explicit sizes and the HIP stream to enqueue on.  No allocation, no synchronisation and no
+ * torch types inside; the caller owns all memory.  Every function returns a hipError_t as int
+ * (0 = hipSuccess; invalid arguments -> hipErrorInvalidValue before anything is launched).
+ *
+ * Tensors are dense fp32 NC[D]HW (the reference's layout).  File:line citations are into the
+ * reference tree.  The ctypes binding that mirrors this header lives in
+ * cost-volume-aggregation-in-stereo-matching-revisited_amd/_lib.py; INTEGRATION.md shows how the
+ * reference's own modules would call it.
+ */
+#ifndef DCA_HIP_H
+#define DCA_HIP_H
+
+#include <hip/hip_runtime_api.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- cost volumes ------------------------------------------------------------------------------
+ * build_gwc_volume(refimg_fea, targetimg_fea, maxdisp, num_groups)  models/submodule.py:157-167
+ * (groupwise_correlation, submodule.py:148-154).  ref,tgt: (B,C,H,W); vol: (B,G,maxdisp,H,W). */
+int dca_gwc_volume_fwd(const float* ref, const float* tgt, float* vol, int B, int C, int H, int W, int maxdisp,
+                       int num_groups, hipStream_t stream);
+/* autograd of the above (the reference back-propagates through maxdisp slice-assign nodes). */
+int dca_gwc_volume_bwd(const float* gvol, const float* ref, const float* tgt, float* gref, float* gtgt, int B, int C,
+                       int H, int W, int maxdisp, int num_groups, hipStream_t stream);
+/* build_concat_volume(refimg_fea, targetimg_fea, maxdisp)  models/submodule.py:134-145; vol: (B,2C,maxdisp,H,W) */
+int dca_concat_volume_fwd(const float* ref, const float* tgt, float* vol, int B, int C, int H, int W, int maxdisp,
+                          hipStream_t stream);
+int dca_concat_volume_bwd(const float* gvol, float* gref, float* gtgt, int B, int C, int H, int W, int maxdisp,
+                          hipStream_t stream);
+
+/* ---- softmax over dim 1 / disparity_regression ---------------------------------------------------
+ * x: (B,K,HW).  mode 0: out (B,K,HW) = F.softmax(x, dim=1)   (models/gwcnet_dca_g.py:238,248,...)
+ *               mode 1: out (B,HW)   = disparity_regression(F.softmax(x,1), K)  (gwcnet_dca_g.py:238-239,263-264)
+ *               mode 2: out (B,HW)   = disparity_regression(x, K)               (models/submodule.py:127-131)
+ * bwd: mode 0: aux = softmax output, g = (B,K,HW); mode 1: aux = logits x, g = (B,HW); mode 2: g = (B,HW). */
+int dca_softargmin_fwd(const float* x, float* out, int B, int K, long HW, int mode, hipStream_t stream);
+int dca_softargmin_bwd(const float* aux, const float* g, float* gx, int B, int K, long HW, int mode,
+                       hipStream_t stream);
+
+/* ---- 3D convolutions (nn.Conv3d / nn.ConvTranspose3d, bias=False) ----------------------------------
+ * models/submodule.py:121-124 (convbn_3d), models/gwcnet_dca_g.py:141-168, models/augment/cva.py:13-55,
+ * models/augment/SelfAttention_bn.py:136-160.
+ *
+ * dca_conv3d_prep_weight re-lays a PyTorch weight out as wt[tap][a][b] (a < Apad contraction channels,
+ * b < Bpad output channels, zero padded), K = 27 or 1 taps:
+ *   src_ab = 0: src is [B][A][K]  (Conv3d weight (Cout,Cin,k,k,k) used forward: A = Cin, B = Cout)
+ *   src_ab = 1: src is [A][B][K]  (ConvTranspose3d weight (Cin,Cout,...) used forward, or a Conv3d
+ *                                  weight used for its backward-data pass: A = Cout, B = Cin)
+ *   flip = 1 reverses the taps (backward-data of a stride-1 convolution).
+ * Padding rules: Apad = Cin rounded up to 8 (ksize 3) or exactly 32/64 (ksize 1);
+ *                Bpad = 32 if (ksize 1 | transposed | (stride 1 & Cout <= 32)) else 64. */
+int dca_conv3d_prep_weight(const float* w, float* wt, int A, int B, int Apad, int Bpad, int K, int src_ab, int flip,
+                           hipStream_t stream);
+/* y = epilogue(conv(x [, x2], wt)).  ksize 3: pad 1, stride 1|2, or transposed (stride 2, pad 1,
+ * output_padding 1).  ksize 1: Cin = 32 or 64; if x2 != NULL the input is cat([x, x2], dim=1) with 32
+ * channels each (cva.py:69 without materialising the cat).  C1 = channels of x when x2 is given.
+ * epilogue(v) = act(v*scale[co] + shift[co] + res_pre) + res_post, act(v) = v > 0 ? v : slope*v
+ * (slope 1: none, 0: ReLU, 0.1: LeakyReLU); scale/shift/res_pre/res_post may be NULL.
+ * Backward-data passes reuse this entry with re-laid-out weights:
+ *   stride-1 conv   -> stride-1 conv,   src_ab = 1, flip = 1
+ *   stride-2 conv   -> transposed conv, src_ab = 1, flip = 0
+ *   transposed conv -> stride-2 conv,   src_ab = 0, flip = 0 */
+int dca_conv3d_forward(const float* x, const float* x2, const float* wt, float* y, const float* scale,
+                       const float* shift, const float* res_pre, const float* res_post, float slope, int N, int Cin,
+                       int C1, int Cout, int CinPad, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int ksize,
+                       int stride, int transposed, hipStream_t stream);
+/* dw[cy*s_cy + cx*s_cx + k] = sum_{n,o} dy[n,cy,o] x[n,cx,stride*o-1+k]  (ksize 3) / sum dy*x (ksize 1).
+ * x: (N,Cx,Di,Hi,Wi), dy: (N,Cy,Do,Ho,Wo).  Conv3d: x = input, dy = grad of output, dw layout
+ * (Cout,Cin,K).  ConvTranspose3d: x = grad of output (fine), dy = input (coarse), stride 2, dw layout
+ * (Cin,Cout,K).  `part` is scratch of dca_conv3d_wgrad_workspace(...) floats. */
+long dca_conv3d_wgrad_workspace(int N, int Cx, int Cy, int Do, int Ho, int Wo, int ksize, int stride);
+int dca_conv3d_wgrad(const float* x, const float* dy, float* part, float* dw, int N, int Cx, int Cy, int Di, int Hi,
+                     int Wi, int Do, int Ho, int Wo, int ksize, int stride, long s_cy, long s_cx, hipStream_t stream);
+
+/* ---- BatchNorm3d + activation + residual -------------------------------------------------------------
+ * nn.BatchNorm3d defaults (eps 1e-5, momentum 0.1) as used by convbn_3d, models/submodule.py:121-124.
+ * dca_bn_stats:    part[(c*nchunk+i)*2+{0,1}] = partial (sum, sum of squares) in double;
+ *                  nchunk = dca_bn_num_chunks(C, S).
+ * dca_bn_finalize: stats = [mean | invstd | scale | shift] (4*C floats); training != 0 uses the batch
+ *                  statistics and updates running_mean/var (unbiased), else uses the running stats.
+ * dca_bn_apply:    z = act(scale*y + shift + res_pre) + res_post.
+ * dca_bn_backward: given dz -> dy (grad of the conv output), dgb = [dgamma | dbeta | ...] (4*C floats),
+ *                  optional g_out = grad w.r.t. res_pre (= dz masked by the activation). */
+int dca_bn_num_chunks(int C, long S);
+int dca_bn_stats(const float* x, double* part, int N, int C, long S, hipStream_t stream);
+int dca_bn_finalize(const double* part, int nchunk, double count, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float momentum, float eps, int training, float* stats,
+                    int C, hipStream_t stream);
+int dca_bn_apply(const float* y, const float* stats, const float* res_pre, const float* res_post, float* z, int N,
+                 int C, long S, float slope, hipStream_t stream);
+int dca_bn_backward(const float* dz, const float* y, const float* res_pre, const float* stats, double* part,
+                    float* dgb, float* dy, float* g_out, int N, int C, long S, float slope, int training,
+                    hipStream_t stream);
+
+/* ---- AvgPool3d((3,3,3), stride 2, padding 1) -- models/augment/cva.py:39 ---------------------------- */
+int dca_avgpool3d_fwd(const float* x, float* y, long NC, int Di, int Hi, int Wi, hipStream_t stream);
+int dca_avgpool3d_bwd(const float* gy, float* gx, long NC, int Di, int Hi, int Wi, hipStream_t stream);
+
+/* ---- F.interpolate(scale_factor=(s,s,s), mode='trilinear'), align_corners=False -----------------------
+ * models/augment/cva.py:64 (s = 2), models/gwcnet_dca_g.py:251,256 (s = 2), :261 (s = 8). */
+int dca_trilinear_fwd(const float* x, float* y, long NC, int Di, int Hi, int Wi, int scale, hipStream_t stream);
+int dca_trilinear_bwd(const float* gy, float* gx, long NC, int Di, int Hi, int Wi, int scale, hipStream_t stream);
+
+/* ---- homogeneous-region context injection -- SemanticLevelContext.forward, semantic_level.py:96-126 ---
+ * x,key: (B,C,n,HW); preds: (B,n,HW) logits.  key = feats_sl + x.  Side outputs (saved for backward):
+ * kstar (B,HW) int32 argmax class, e (B,HW), pm (B,HW) = p[k*], denom (B,n). */
+int dca_context_inject_fwd(const float* x, const float* preds, float* key, int* kstar, float* e, float* pm,
+                           float* denom, int B, int C, int n, long HW, hipStream_t stream);
+int dca_context_inject_bwd(const float* dkey, const float* x, const float* preds, const int* kstar, const float* e,
+                           const float* pm, const float* denom, float* dx, float* dpreds, float* dw, float* T, int B,
+                           int C, int n, long HW, hipStream_t stream);
+
+/* ---- per-pixel disparity attention core -- SelfAttentionBlock.forward, SelfAttention_bn.py:70-94 ------
+ * q,k,v,out: (B,C,n,HW), heads of 8 channels, softmax(q k^T / sqrt(8)) v over the n bins (n <= 32). */
+int dca_disp_attention_fwd(const float* q, const float* k, const float* v, float* out, int B, int C, int n, long HW,
+                           hipStream_t stream);
+int dca_disp_attention_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq, float* dk,
+                           float* dv, int B, int C, int n, long HW, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCA_HIP_H */

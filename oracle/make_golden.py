@@ -214,10 +214,22 @@ def gen_hot_path():
                 npz(stem, pred4_q=pred4, prob_volume2=prob2, gfL=g[0][:, ::16], gfR=g[1][:, ::16])
 
 
+def gen_state_dict_keys():
+    """Key names + shapes of the reference model's state dict (the on-disk checkpoint format, main_dca.py:58-61)."""
+    import json
+    out = {}
+    for variant, concat in (("g", False), ("gc", True)):
+        m = ref_dca.GwcNet(192, use_concat_volume=concat)
+        out[variant] = {k: list(v.shape) for k, v in m.state_dict().items()}
+    with open(os.path.join(OUT, "state_dict_keys.json"), "w") as f:
+        json.dump(out, f)
+    print("state_dict_keys:", {k: len(v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["volumes", "inject", "attention", "cva", "magg", "hot"]
+    which = sys.argv[1:] or ["volumes", "inject", "attention", "cva", "magg", "hot", "keys"]
     with torch.enable_grad():
         if "volumes" in which: gen_volumes()
         if "inject" in which: gen_context_inject()
@@ -225,3 +237,4 @@ if __name__ == "__main__":
         if "cva" in which: gen_cva()
         if "magg" in which: gen_multi_agg_hourglass()
         if "hot" in which: gen_hot_path()
+        if "keys" in which: gen_state_dict_keys()

@@ -1,0 +1,426 @@
+"""GPU parity: every HIP kernel (through the C ABI / ctypes) against the CPU oracle on the same seeded
+inputs, then whole modules against the golden vectors generated from the reference.
+
+Tolerances (fp32 path, north_star: 1e-3 abs on the disparity): kernel-level max-abs <= 2e-5 * scale for
+forward results (fp32 MFMA is an exact fma chain; only summation order differs), relative-L2 <= 1e-4
+for gradients of single ops, and the end-to-end gates documented in tests/test_oracle_golden.py."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import dcanet_oracle as O
+from oracle.seeded import seeded_tensor, thin
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _mods():
+    import dcanet_amd
+    from dcanet_amd import ops
+    return dcanet_amd, ops
+
+
+def close(a, b, tol=2e-5, name=""):
+    a, b = torch.as_tensor(a).detach().cpu().double(), torch.as_tensor(b).detach().cpu().double()
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    err = (a - b).abs().max().item()
+    scale = max(1.0, b.abs().max().item())
+    assert err <= tol * scale, f"{name}: max err {err:.3e} (scale {scale:.3e})"
+
+
+def close_l2(a, b, rel=1e-4, name=""):
+    a, b = torch.as_tensor(a).detach().cpu().double(), torch.as_tensor(b).detach().cpu().double()
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    err = ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+    assert err <= rel, f"{name}: rel L2 err {err:.3e}"
+
+
+def gpu(t, grad=False):
+    return t.detach().to(DEV).requires_grad_(grad)
+
+
+def cpu_leaf(t):
+    return t.detach().clone().requires_grad_()
+
+
+# ------------------------------------------------------------------------------------- volumes
+@pytest.mark.parametrize("shape", [(2, 32, 4, 5, 18, 6), (1, 320, 40, 3, 10, 12), (1, 320, 40, 6, 64, 16),
+                                   (2, 64, 8, 7, 40, 48)])
+def test_gwc_volume(shape):
+    _, ops = _mods()
+    B, C, G, H, W, D = shape
+    L, R = seeded_tensor("g.L", (B, C, H, W)), seeded_tensor("g.R", (B, C, H, W))
+    gv = seeded_tensor("g.gv", (B, G, D, H, W))
+    Lc, Rc = cpu_leaf(L), cpu_leaf(R)
+    vr = O.build_gwc_volume(Lc, Rc, D, G)
+    gLr, gRr = torch.autograd.grad((vr * gv).sum(), [Lc, Rc])
+    Lg, Rg = gpu(L, True), gpu(R, True)
+    v = ops.gwc_volume(Lg, Rg, D, G)
+    gL, gR = torch.autograd.grad((v * gv.to(DEV)).sum(), [Lg, Rg])
+    close(v, vr, 2e-6, "gwc")
+    close(gL, gLr, 1e-5, "gL"); close(gR, gRr, 1e-5, "gR")
+
+
+@pytest.mark.parametrize("shape", [(2, 12, 5, 18, 6), (1, 12, 6, 64, 16)])
+def test_concat_volume(shape):
+    _, ops = _mods()
+    B, C, H, W, D = shape
+    L, R = seeded_tensor("c.L", (B, C, H, W)), seeded_tensor("c.R", (B, C, H, W))
+    gv = seeded_tensor("c.gv", (B, 2 * C, D, H, W))
+    Lc, Rc = cpu_leaf(L), cpu_leaf(R)
+    vr = O.build_concat_volume(Lc, Rc, D)
+    gLr, gRr = torch.autograd.grad((vr * gv).sum(), [Lc, Rc])
+    Lg, Rg = gpu(L, True), gpu(R, True)
+    v = ops.concat_volume(Lg, Rg, D)
+    gL, gR = torch.autograd.grad((v * gv.to(DEV)).sum(), [Lg, Rg])
+    close(v, vr, 0, "concat"); close(gL, gLr, 1e-6); close(gR, gRr, 1e-6)
+
+
+def test_golden_volumes(golden):
+    """the reference's own outputs (tests/golden/volumes_*.npz)"""
+    dm, ops = _mods()
+    from dcanet_amd.models.submodule import build_concat_volume, build_gwc_volume, disparity_regression
+    for tag in ("t0", "t1"):
+        g = golden(f"volumes_{tag}")
+        B, C, G, H, W, D, cc = [int(v) for v in g["shape"]]
+        L = gpu(seeded_tensor(f"vol.{tag}.L", (B, C, H, W)), True)
+        R = gpu(seeded_tensor(f"vol.{tag}.R", (B, C, H, W)), True)
+        v = build_gwc_volume(L, R, D, G)
+        close(v, g["gwc"], 2e-6, "gwc")
+        gL, gR = torch.autograd.grad((v * seeded_tensor(f"vol.{tag}.gv", v.shape).to(DEV)).sum(), [L, R])
+        close(gL, g["gL"], 1e-5); close(gR, g["gR"], 1e-5)
+        cv = build_concat_volume(L[:, :cc].detach(), R[:, :cc].detach(), D)
+        close(cv, g["concat"], 0)
+    g = golden("regression")
+    close(disparity_regression(torch.from_numpy(g["p"]).to(DEV), 8), g["disp"], 1e-6)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_softargmin(mode):
+    _, ops = _mods()
+    x = seeded_tensor("sa.x", (2, 12, 5, 9)) * 2
+    xc = cpu_leaf(x)
+    if mode == 0:
+        yr = F.softmax(xc, 1)
+    elif mode == 1:
+        yr = O.disparity_regression(F.softmax(xc, 1), 12)
+    else:
+        yr = O.disparity_regression(xc, 12)
+    gy = seeded_tensor("sa.g", yr.shape)
+    (gxr,) = torch.autograd.grad((yr * gy).sum(), [xc])
+    xg = gpu(x, True)
+    y = [ops.softmax_dim1, ops.softargmin, ops.regression][mode](xg)
+    (gx,) = torch.autograd.grad((y * gy.to(DEV)).sum(), [xg])
+    close(y, yr, 2e-6, "fwd"); close(gx, gxr, 1e-5, "bwd")
+
+
+# ------------------------------------------------------------------------------------- convolutions
+CONV_CASES = [
+    # cin, cout, k, stride, transposed, dims, N
+    (40, 32, 3, 1, False, (4, 6, 10), 2),
+    (40, 32, 3, 1, False, (3, 9, 36), 1),
+    (64, 32, 3, 1, False, (4, 8, 40), 1),
+    (32, 32, 3, 1, False, (5, 10, 68), 2),
+    (32, 1, 3, 1, False, (4, 6, 12), 2),
+    (64, 64, 3, 1, False, (4, 6, 36), 1),
+    (32, 64, 3, 2, False, (4, 8, 20), 2),
+    (32, 64, 3, 2, False, (8, 12, 72), 1),
+    (64, 32, 3, 2, True, (2, 3, 5), 2),
+    (64, 32, 3, 2, True, (4, 5, 36), 1),
+    (32, 32, 1, 1, False, (4, 6, 10), 2),
+    (32, 32, 1, 1, False, (3, 5, 9), 1),
+    (64, 32, 1, 1, False, (4, 6, 12), 2),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[str(c[:5]) + str(c[5]) for c in CONV_CASES])
+def test_conv3d(case):
+    _, ops = _mods()
+    cin, cout, k, stride, transposed, dims, N = case
+    x = seeded_tensor(f"cv.x{case}", (N, cin) + dims)
+    wshape = (cin, cout, k, k, k) if transposed else (cout, cin, k, k, k)
+    w = seeded_tensor(f"cv.w{case}", wshape) * (1.0 / (cin * k ** 3) ** 0.5)
+    xc, wc = cpu_leaf(x), cpu_leaf(w)
+    if transposed:
+        yr = F.conv_transpose3d(xc, wc, None, 2, 1, 1)
+    else:
+        yr = F.conv3d(xc, wc, None, stride, k // 2)
+    gy = seeded_tensor(f"cv.g{case}", yr.shape)
+    gxr, gwr = torch.autograd.grad((yr * gy).sum(), [xc, wc])
+    xg, wg = gpu(x, True), gpu(w, True)
+    y = ops.conv3d(xg, wg, stride, transposed)
+    close(y, yr, 1e-5, "fwd")
+    gx, gw = torch.autograd.grad((y * gy.to(DEV)).sum(), [xg, wg])
+    close(gx, gxr, 1e-5, "dx"); close_l2(gx, gxr, 1e-5, "dx")
+    close_l2(gw, gwr, 1e-5, "dw"); close(gw, gwr, 2e-5, "dw")
+
+
+def test_conv1x1_two_inputs():
+    _, ops = _mods()
+    dims, N = (4, 6, 12), 2
+    a, b = seeded_tensor("c2.a", (N, 32) + dims), seeded_tensor("c2.b", (N, 32) + dims)
+    w = seeded_tensor("c2.w", (32, 64, 1, 1, 1)) * 0.2
+    ac, bc, wc = cpu_leaf(a), cpu_leaf(b), cpu_leaf(w)
+    yr = F.conv3d(torch.cat([ac, bc], 1), wc)
+    gy = seeded_tensor("c2.g", yr.shape)
+    gar, gbr, gwr = torch.autograd.grad((yr * gy).sum(), [ac, bc, wc])
+    ag, bg, wg = gpu(a, True), gpu(b, True), gpu(w, True)
+    y = ops.conv3d(ag, wg, 1, False, x2=bg)
+    ga, gb, gw = torch.autograd.grad((y * gy.to(DEV)).sum(), [ag, bg, wg])
+    close(y, yr, 1e-5); close(ga, gar, 1e-5); close(gb, gbr, 1e-5); close_l2(gw, gwr, 1e-5)
+
+
+def _bn_ref(y, gamma, beta, rm, rv, training, slope, res_pre, res_post):
+    z = F.batch_norm(y, rm, rv, gamma, beta, training, 0.1, 1e-5)
+    if res_pre is not None:
+        z = z + res_pre
+    z = F.leaky_relu(z, slope) if slope != 1.0 else z
+    if res_post is not None:
+        z = z + res_post
+    return z
+
+
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("slope,pre,post", [(0.0, False, False), (0.1, False, False), (1.0, False, True),
+                                            (0.0, True, True), (1.0, True, False)])
+@pytest.mark.parametrize("shape", [(2, 32, 4, 6, 12), (1, 64, 3, 5, 9)])
+def test_bn_act(training, slope, pre, post, shape):
+    _, ops = _mods()
+    C = shape[1]
+    y = seeded_tensor("bn.y", shape) * 1.7 + 0.3
+    gamma, beta = torch.rand(C, generator=torch.Generator().manual_seed(1)) + 0.5, seeded_tensor("bn.b", (C,)) * 0.2
+    rm, rv = seeded_tensor("bn.rm", (C,)) * 0.1, torch.rand(C, generator=torch.Generator().manual_seed(2)) + 0.5
+    rp = seeded_tensor("bn.rp", shape) if pre else None
+    rq = seeded_tensor("bn.rq", shape) if post else None
+    gz = seeded_tensor("bn.gz", shape)
+    # oracle
+    yc, gc, bc = cpu_leaf(y), cpu_leaf(gamma), cpu_leaf(beta)
+    rpc = cpu_leaf(rp) if pre else None
+    rqc = cpu_leaf(rq) if post else None
+    rmc, rvc = rm.clone(), rv.clone()
+    zr = _bn_ref(yc, gc, bc, rmc, rvc, training, slope, rpc, rqc)
+    wrt = [yc, gc, bc] + ([rpc] if pre else []) + ([rqc] if post else [])
+    gr = torch.autograd.grad((zr * gz).sum(), wrt)
+    # HIP
+    bn = torch.nn.BatchNorm3d(C).to(DEV)
+    with torch.no_grad():
+        bn.weight.copy_(gamma); bn.bias.copy_(beta); bn.running_mean.copy_(rm); bn.running_var.copy_(rv)
+    bn.train(training)
+    yg = gpu(y, True)
+    rpg = gpu(rp, True) if pre else None
+    rqg = gpu(rq, True) if post else None
+    z = ops.bn_act(yg, bn, slope, rpg, rqg)
+    wrt_g = [yg, bn.weight, bn.bias] + ([rpg] if pre else []) + ([rqg] if post else [])
+    gg = torch.autograd.grad((z * gz.to(DEV)).sum(), wrt_g)
+    close(z, zr, 1e-5, "z")
+    for a, b, nm in zip(gg, gr, ["dy", "dgamma", "dbeta", "dres1", "dres2"]):
+        close(a, b, 2e-5, nm)
+    close(bn.running_mean, rmc, 1e-6, "running_mean"); close(bn.running_var, rvc, 1e-6, "running_var")
+    assert int(bn.num_batches_tracked) == (1 if training else 0)
+
+
+def test_convbn_fused_inference_matches_unfused():
+    _, ops = _mods()
+    from dcanet_amd.models.submodule import ConvBn3d
+    m = ConvBn3d(32, 32, 3, 1, 1).to(DEV).eval()
+    with torch.no_grad():
+        m[1].running_mean.normal_(0, 0.1); m[1].running_var.uniform_(0.5, 1.5); m[1].weight.uniform_(0.5, 1.5)
+        m[1].bias.normal_(0, 0.1)
+    x = seeded_tensor("fi.x", (2, 32, 4, 6, 36)).to(DEV)
+    r1, r2 = seeded_tensor("fi.r1", (2, 32, 4, 6, 36)).to(DEV), seeded_tensor("fi.r2", (2, 32, 4, 6, 36)).to(DEV)
+    with torch.no_grad():
+        fused = m(x, slope=0.0, res_pre=r1, res_post=r2)
+    unfused = m(x.requires_grad_(), slope=0.0, res_pre=r1, res_post=r2)
+    ref = F.relu(F.batch_norm(F.conv3d(x.detach().cpu(), m[0].weight.detach().cpu(), None, 1, 1),
+                              m[1].running_mean.cpu(), m[1].running_var.cpu(), m[1].weight.detach().cpu(),
+                              m[1].bias.detach().cpu(), False, 0.1, 1e-5) + r1.cpu()) + r2.cpu()
+    close(fused, ref, 1e-5, "fused"); close(unfused, ref, 1e-5, "unfused")
+
+
+# ------------------------------------------------------------------------------------- pool / interp
+@pytest.mark.parametrize("dims", [(4, 6, 10), (5, 7, 9), (8, 8, 16)])
+def test_avgpool(dims):
+    _, ops = _mods()
+    x = seeded_tensor("ap.x", (2, 3) + dims)
+    xc = cpu_leaf(x)
+    yr = F.avg_pool3d(xc, (3, 3, 3), stride=2, padding=1)
+    gy = seeded_tensor("ap.g", yr.shape)
+    (gxr,) = torch.autograd.grad((yr * gy).sum(), [xc])
+    xg = gpu(x, True)
+    y = ops.avg_pool3d_k3s2p1(xg)
+    (gx,) = torch.autograd.grad((y * gy.to(DEV)).sum(), [xg])
+    close(y, yr, 1e-6); close(gx, gxr, 1e-6)
+
+
+@pytest.mark.parametrize("scale,dims", [(2, (2, 3, 5)), (2, (4, 6, 10)), (8, (2, 2, 3)), (8, (1, 3, 4))])
+def test_trilinear(scale, dims):
+    _, ops = _mods()
+    x = seeded_tensor("tl.x", (2, 3) + dims)
+    xc = cpu_leaf(x)
+    yr = F.interpolate(xc, scale_factor=(scale,) * 3, mode="trilinear")
+    gy = seeded_tensor("tl.g", yr.shape)
+    (gxr,) = torch.autograd.grad((yr * gy).sum(), [xc])
+    xg = gpu(x, True)
+    y = ops.trilinear_upsample(xg, scale)
+    (gx,) = torch.autograd.grad((y * gy.to(DEV)).sum(), [xg])
+    close(y, yr, 2e-6); close(gx, gxr, 1e-5)
+
+
+# ------------------------------------------------------------------------------------- DCA units
+@pytest.mark.parametrize("shape", [(2, 32, 4, 8, 16), (1, 32, 6, 5, 9), (2, 32, 24, 9, 30)])
+def test_context_inject(shape):
+    _, ops = _mods()
+    x = seeded_tensor("ci.x", shape)
+    p = seeded_tensor("ci.p", (shape[0],) + shape[2:]) * 1.5
+    g = seeded_tensor("ci.g", shape)
+    xc, pc = cpu_leaf(x), cpu_leaf(p)
+    keyr, kr, _ = O.context_inject(xc, pc)
+    gxr, gpr = torch.autograd.grad((keyr * g).sum(), [xc, pc])
+    xg, pg = gpu(x, True), gpu(p, True)
+    key, ks = ops.context_inject(xg, pg)
+    gx, gp = torch.autograd.grad((key * g.to(DEV)).sum(), [xg, pg])
+    assert (ks.cpu().view(kr.shape).long() == kr).all(), "argmax classes differ"
+    close(key, keyr, 2e-6, "key"); close(gx, gxr, 2e-6, "gx"); close(gp, gpr, 2e-5, "gpreds")
+
+
+def test_golden_context_inject(golden):
+    _, ops = _mods()
+    for tag in ("t0", "t1"):
+        g = golden(f"context_inject_{tag}")
+        shp = tuple(int(v) for v in g["shape"])
+        x = gpu(seeded_tensor(f"inj.{tag}.x", shp), True)
+        preds = gpu(seeded_tensor(f"inj.{tag}.p", (shp[0],) + shp[2:]) * 1.5, True)
+        key, ks = ops.context_inject(x, preds)
+        mism = (ks.cpu().view(g["kstar"].shape).numpy() != g["kstar"]).sum()
+        assert mism == 0, f"{mism} argmax mismatches"
+        close(key, g["key"], 2e-6)
+        gx, gp = torch.autograd.grad((key * seeded_tensor(f"inj.{tag}.g", shp).to(DEV)).sum(), [x, preds])
+        close(gx, g["gx"], 2e-6); close(gp, g["gp"], 2e-5)
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 4, 6, 10), (1, 32, 24, 5, 13), (1, 32, 9, 4, 40), (1, 16, 32, 3, 7)])
+def test_attention_core(shape):
+    _, ops = _mods()
+    q, k, v = (seeded_tensor(f"at.{n}", shape) for n in "qkv")
+    g = seeded_tensor("at.g", shape)
+    qc, kc, vc = cpu_leaf(q), cpu_leaf(k), cpu_leaf(v)
+    outr = O.disparity_attention_core(qc, kc, vc)
+    gr = torch.autograd.grad((outr * g).sum(), [qc, kc, vc])
+    qg, kg, vg = gpu(q, True), gpu(k, True), gpu(v, True)
+    out = ops.disparity_attention(qg, kg, vg)
+    gg = torch.autograd.grad((out * g.to(DEV)).sum(), [qg, kg, vg])
+    close(out, outr, 5e-6, "out")
+    for a, b, nm in zip(gg, gr, ["dq", "dk", "dv"]):
+        close(a, b, 1e-5, nm)
+
+
+# ------------------------------------------------------------------------------------- modules vs golden
+def load_seeded(module):
+    shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+    sd = O.seeded_state_dict(shapes)
+    module.load_state_dict(sd, strict=True)
+    return module
+
+
+def grads_of(outs, tags, wrt):
+    loss = 0
+    for o, tag in zip(outs, tags):
+        loss = loss + (o * seeded_tensor(tag, o.shape).to(o.device)).sum()
+    return torch.autograd.grad(loss, wrt, allow_unused=True)
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_golden_attention_block(golden, training):
+    from dcanet_amd.models.augment.semantic_level import SemanticLevelContext
+    g = golden(f"attention_{'train' if training else 'eval'}")
+    att = load_seeded(SemanticLevelContext(32, 32).cross_attention).to(DEV).train(training)
+    shp = tuple(int(v) for v in g["shape"])
+    q, k = gpu(seeded_tensor("att.q", shp), True), gpu(seeded_tensor("att.k", shp), True)
+    out = att(q, k)
+    close(out, g["out"], 2e-5, "out")
+    params = [att.query_project[0][0].weight, att.value_project[0].weight, att.out_project[1].weight,
+              att.key_project[1][1].bias]
+    gr = grads_of([out], ["att.g"], [q, k] + params)
+    for got, name in zip(gr, ["gq", "gk", "g_qp00w", "g_vp0w", "g_op1w", "g_kp11b"]):
+        close_l2(thin(got) if name.startswith("g_") else got, g[name], 2e-4, name)
+    close(att.query_project[0][1].running_mean, g["rm_after"], 1e-6)
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_golden_multi_agg(golden, training):
+    from dcanet_amd.models.augment.cva import Multi_Aggregation
+    g = golden(f"multi_agg_{'train' if training else 'eval'}")
+    m = load_seeded(Multi_Aggregation(32)).to(DEV).train(training)
+    x = gpu(seeded_tensor("magg.x", (2, 32, 4, 6, 10)), True)
+    y = m(x)
+    close(y, g["y"], 2e-5)
+    gr = grads_of([y], ["magg.g"], [x, m.conv3[0].weight, m.conv1[0][0].weight, m.redir[0].weight])
+    for got, name in zip(gr, ["gx", "g_w3", "g_w1", "g_wr"]):
+        close_l2(thin(got) if name.startswith("g_") else got, g[name], 2e-4, name)
+
+
+@pytest.mark.parametrize("training", [False, True])
+@pytest.mark.parametrize("tag", ["t0", "t1"])
+def test_golden_cva(golden, tag, training):
+    from dcanet_amd.models.augment.cva import cva
+    g = golden(f"cva_{tag}_{'train' if training else 'eval'}")
+    m = load_seeded(cva(32, 32)).to(DEV).train(training)
+    shp = tuple(int(v) for v in g["shape"])
+    x = gpu(seeded_tensor(f"cva.{tag}.x", shp), True)
+    prob, aug = m(x)
+    close(prob, g["prob"], 2e-5, "prob"); close(aug, g["aug"], 2e-5, "aug")
+    params = [m.downsample[1][0].weight, m.classify[2].weight, m.fuse[0][0].weight, m.cost_agg.conv1[0][0].weight,
+              m.cost_agg.conv3[0].weight, m.cost_agg.conv3[1].weight, m.cost_agg.redir[1].bias,
+              m.slc_net.cross_attention.key_project[0][0].weight]
+    gr = grads_of([prob, aug], [f"cva.{tag}.gprob", f"cva.{tag}.gaug"], [x] + params)
+    gn = ["gx", "g_down_w", "g_cls2_w", "g_fuse_w", "g_agg1_w", "g_agg3_w", "g_agg3_bnw", "g_redir_bnb", "g_kp00_w"]
+    for got, name in zip(gr, gn):
+        close_l2(thin(got) if name.startswith("g_") else got, g[name], 1e-3, name)
+    close(m.cost_agg.conv3[1].running_var, g["rv_after"], 1e-5)
+
+
+@pytest.mark.parametrize("variant", ["g", "gc"])
+@pytest.mark.parametrize("training", [False, True])
+def test_golden_hot_path(golden, variant, training):
+    """The reference's GwcNet.forward body (gwcnet_dca_g.py:216-278) from 1/4-res features, D=32."""
+    from dcanet_amd.models.gwcnet_dca_g import GwcNet
+    concat = variant == "gc"
+    g = golden(f"hot_path_{variant}_{'train' if training else 'eval'}")
+    m = load_seeded(GwcNet(32, use_concat_volume=concat)).to(DEV).train(training)
+    C = 320 + (12 if concat else 0)
+    fL, fR = gpu(seeded_tensor("hot.fL", (2, C, 16, 32)), True), gpu(seeded_tensor("hot.fR", (2, C, 16, 32)), True)
+    if concat:
+        r = m.hot_path(fL[:, :320], fR[:, :320], fL[:, 320:], fR[:, 320:])
+    else:
+        r = m.hot_path(fL, fR)
+    close(r["pred4_q"], g["pred4_q"], 1e-3 / 8, "pred4_q (1e-3 abs on a 0..7 range)")
+    if training:
+        keys = ["pred0", "pred_dca1", "pred_dca2", "pred1", "pred2", "pred_dca3", "pred4_q"]
+        for k in keys:
+            close(r[k], g[k], 2e-5, k)
+        params = [m.dres0[0][0].weight, m.dres1[2][1].weight, m.cva2.cost_agg.conv3[0].weight,
+                  m.cva1.slc_net.cross_attention.query_project[0][0].weight, m.classif3[2].weight,
+                  m.cva3.fuse[0][1].bias, m.classif1[0][0].weight]
+        gr = grads_of([r[k] for k in keys], [f"hot.g{i}" for i in range(7)], [fL, fR] + params)
+        close_l2(gr[0][:, ::16], g["gfL"], 2e-3, "gfL"); close_l2(gr[1][:, ::16], g["gfR"], 2e-3, "gfR")
+        gn = ["g_dres0_w", "g_dres1_bn2_w", "g_cva2_deconv_w", "g_cva1_q00_w", "g_cls3_w", "g_cva3_fuse_bnb",
+              "g_cls1_w"]
+        for got, name in zip(gr[2:], gn):
+            close_l2(thin(got), g[name], 1e-2 if name.endswith("bnb") else 2e-3, name)
+        close(m.dres0[0][1].running_mean, g["rm_dres0"], 1e-5)
+    else:
+        close(r["prob_volume2"].squeeze(1), g["prob_volume2"], 2e-5, "prob_volume2")
+        gr = grads_of([r["pred4_q"]], ["hot.g_eval"], [fL, fR])
+        close_l2(gr[0][:, ::16], g["gfL"], 1e-3); close_l2(gr[1][:, ::16], g["gfR"], 1e-3)
+        with torch.no_grad():   # fused inference path (BN folded into the conv epilogues)
+            r2 = m.hot_path(fL[:, :320], fR[:, :320], fL[:, 320:], fR[:, 320:]) if concat else m.hot_path(fL, fR)
+        close(r2["pred4_q"], g["pred4_q"], 1e-3 / 8, "pred4_q fused")
+
+
+def test_cpu_tensors_raise():
+    _, ops = _mods()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.gwc_volume(torch.zeros(1, 8, 2, 4), torch.zeros(1, 8, 2, 4), 2, 1)

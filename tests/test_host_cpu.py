@@ -1,0 +1,80 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol include/dca_hip.h
+declares (no compute calls without a GPU), the module mirror has the reference's state-dict format, and the
+product path refuses to run without the HIP kernels (no CPU fallback)."""
+import json
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_capi_exports_every_declared_symbol():
+    import dcanet_amd
+    from dcanet_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "dca_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|long)\s+(dca_\w+)\s*\(", header, flags=re.M))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_capi_argument_counts_match_header():
+    from dcanet_amd import _lib
+    header = open(os.path.join(ROOT, "include", "dca_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    for name, (_, args) in _lib.SIGNATURES.items():
+        m = re.search(name + r"\s*\((.*?)\)\s*;", header, flags=re.S)
+        assert m, name
+        assert len([a for a in m.group(1).split(",") if a.strip()]) == len(args), name
+
+
+@pytest.mark.parametrize("variant", ["g", "gc"])
+def test_state_dict_matches_reference(variant):
+    """tests/golden/state_dict_keys.json was dumped from the reference model (oracle/make_golden.py)."""
+    from dcanet_amd.models.gwcnet_dca_g import GwcNet
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_keys.json")))[variant]
+    got = {k: list(v.shape) for k, v in GwcNet(192, use_concat_volume=(variant == "gc")).state_dict().items()}
+    assert list(got) == list(want)          # same keys, same order
+    assert got == want                      # same shapes
+
+
+def test_factories_and_registry():
+    from dcanet_amd.models import __models__, GwcNet_G, GwcNet_GC
+    assert __models__["gwcnet-g"] is GwcNet_G and __models__["gwcnet-gc"] is GwcNet_GC
+    m = GwcNet_G(64)
+    assert m.maxdisp == 64 and m.num_groups == 40 and m.concat_channels == 0 and not m.use_concat_volume
+    assert GwcNet_GC(64).concat_channels == 12
+
+
+def test_no_cpu_fallback():
+    from dcanet_amd.models.submodule import build_gwc_volume, disparity_regression
+    from dcanet_amd.models.gwcnet_dca_g import GwcNet
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        build_gwc_volume(torch.zeros(1, 8, 2, 4), torch.zeros(1, 8, 2, 4), 2, 1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        disparity_regression(torch.zeros(1, 4, 2, 2), 4)
+    m = GwcNet(32, False).eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"), torch.no_grad():
+        m(torch.zeros(1, 3, 32, 64), torch.zeros(1, 3, 32, 64))
+
+
+def test_reference_asserts_are_kept():
+    from dcanet_amd.models.submodule import build_gwc_volume, disparity_regression
+    with pytest.raises(AssertionError):
+        disparity_regression(torch.zeros(4, 2, 2), 4)          # reference submodule.py:128
+    with pytest.raises(AssertionError):
+        build_gwc_volume(torch.zeros(1, 9, 2, 4), torch.zeros(1, 9, 2, 4), 2, 4)   # submodule.py:150
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "cost-volume-aggregation-in-stereo-matching-revisited_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src, os.path.join(dirpath, f)
