@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""DCANet cost-volume hot path benchmark on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--mode fwdbwd|fwd] [--batch B]
+
+One *step* = one pass of the hot path over one batch of synthetic SceneFlow-test-shaped input
+(544x960, D=192 -> 1/4-res features (B,320,136,240) x2, seed 1234+rank, already resident in HBM):
+
+  fwdbwd (default, BASELINE.json's metric "cost-volumes/sec (fwd+bwd)"):
+      the reference's training step from the features on -- train-mode forward with all auxiliary heads
+      (gwcnet_dca_g.py:216-278), the convex up-sampler, focal_loss + model_loss (main_dca.py:132-133),
+      backward to the features and all parameters, ONE all-reduce of the flat fp32 gradient bucket (RCCL),
+      Adam step (main_dca.py:64).
+  fwd: eval-mode forward only (BASELINE config[1]), BN folded into the conv epilogues.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
+measured live with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle on the host cores,
+rank 0 / N=1 only, on a bounded sample).
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H_IMG, W_IMG, MAXDISP = 544, 960, 192
+PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def build_model(device):
+    import dcanet_amd  # noqa: F401
+    from dcanet_amd.models.gwcnet_dca_g import GwcNet
+    torch.manual_seed(1)
+    m = GwcNet(MAXDISP, use_concat_volume=False)       # "GwcNet-G" variant named by BASELINE configs
+    # synthetic BN statistics / affine so eval mode is well conditioned
+    g = torch.Generator().manual_seed(2)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, (torch.nn.BatchNorm2d, torch.nn.BatchNorm3d)):
+                mod.weight.copy_(torch.rand(mod.weight.shape, generator=g) * 0.5 + 0.75)
+                mod.bias.copy_(torch.randn(mod.bias.shape, generator=g) * 0.1)
+                mod.running_mean.copy_(torch.randn(mod.bias.shape, generator=g) * 0.1)
+                mod.running_var.copy_(torch.rand(mod.bias.shape, generator=g) * 0.5 + 0.75)
+    return m.to(device)
+
+
+def hot_params(m):
+    mods = [m.dres0, m.dres1, m.cva1, m.cva2, m.cva3, m.classif0, m.classif1, m.classif2, m.classif3, m.prop]
+    return [p for mod in mods for p in mod.parameters()]
+
+
+def make_inputs(batch, rank, device, h4=H_IMG // 4, w4=W_IMG // 4):
+    g = torch.Generator().manual_seed(1234 + rank)
+    fL = torch.randn(batch, 320, h4, w4, generator=g).to(device)
+    fR = torch.randn(batch, 320, h4, w4, generator=g).to(device)
+    guid = torch.randn(batch, 64, h4, w4, generator=g).to(device)
+    gt = (torch.rand(batch, 1, 4 * h4, 4 * w4, generator=g) * 190.0 + 1.0).to(device)
+    return fL, fR, guid, gt
+
+
+def train_step(m, fL, fR, guid, gt, bucket, opt):
+    from dcanet_amd.models.loss import focal_loss, model_loss
+    bucket.zero()
+    fL.grad = fR.grad = None
+    r = m.hot_path(fL, fR)
+    pred4 = m.prop(guid, r["pred4_q"])
+    mask = (gt < MAXDISP) & (gt > 0)
+    loss = focal_loss([r["pred0"], r["pred_dca1"], r["pred_dca2"], r["pred1"], r["pred2"]], gt, MAXDISP, 5.0, False) \
+        + model_loss([r["pred_dca3"], pred4], gt, mask)
+    loss.backward()
+    bucket.all_reduce_mean()
+    opt.step()
+    return loss
+
+
+def eval_step(m, fL, fR, guid):
+    with torch.no_grad():
+        r = m.hot_path(fL, fR)
+        return m.prop(guid, r["pred4_q"])
+
+
+def kernel_roofline(device):
+    """Dominant kernels timed live with HIP events on the launch stream (torch's current stream is the stream
+    the C ABI launches on).  conv3_mfma_kernel<1,1,8,2,8>: 3x3x3 32->32 at 1/4 res (used by dres0/1,
+    classif*, and every stride-1 backward-data pass); wgrad3_kernel<1>: its weight gradient."""
+    from dcanet_amd import ops
+    d, h, w = MAXDISP // 4, H_IMG // 4, W_IMG // 4
+    x = torch.randn(1, 32, d, h, w, device=device)
+    wgt = torch.randn(32, 32, 3, 3, 3, device=device) * 0.05
+    flops = 2.0 * 27 * 32 * 32 * d * h * w
+    out = {}
+    with torch.no_grad():
+        wt, cpad = ops._prep_weight(wgt, 32, 32, 27, 0, 0, 3, 1, False)
+        for name, fn in (("conv3_mfma_kernel<S1,Cout32,CK8,2x8x32> (3x3x3 32->32 @1/4 res)",
+                          lambda: ops._conv_launch(x, None, wt, cpad, 32, 32, 32, 3, 1, False)),
+                         ("wgrad3_kernel<S1> (+reduce) (dW of 3x3x3 32->32 @1/4 res)",
+                          lambda: ops._wgrad(x, x, wgt.new_empty(wgt.shape), 0, 32, 32, 3, 1, 32 * 27, 27))):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            reps = 10
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            out[name] = {"bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 2),
+                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(flops / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "ms_per_launch": round(ms, 4), "flop_per_launch": flops}
+    return out
+
+
+def cpu_baseline(m, mode, rows_q=34):
+    """The CPU oracle (torch CPU restatement of the reference, oracle/dcanet_oracle.py) timed on the host cores
+    on a bounded sample: the same workload cropped to `rows_q` of the 136 quarter-res rows (full width, full
+    disparity range), one iteration, scaled by the row fraction."""
+    from oracle import dcanet_oracle as O
+    from dcanet_amd.models.loss import focal_loss, model_loss
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()
+          if k.split(".")[0] in ("dres0", "dres1", "cva1", "cva2", "cva3", "classif0", "classif1", "classif2",
+                                 "classif3")}
+    prop = copy.deepcopy(m.prop).cpu()
+    fL, fR, guid, gt = make_inputs(1, 0, "cpu", rows_q, W_IMG // 4)
+    threads = torch.get_num_threads()
+    t0 = time.time()
+    if mode == "fwd":
+        with torch.no_grad():
+            prop.eval()
+            r = O.hot_path(sd, fL, fR, MAXDISP, False)
+            prop(guid, r["pred4_q"])
+    else:
+        for k in sd:
+            if sd[k].is_floating_point() and "running" not in k:
+                sd[k].requires_grad_()
+        fL.requires_grad_(); fR.requires_grad_()
+        r = O.hot_path(sd, fL, fR, MAXDISP, True)
+        pred4 = prop.train()(guid, r["pred4_q"])
+        mask = (gt < MAXDISP) & (gt > 0)
+        loss = focal_loss([r["pred0"], r["pred_dca1"], r["pred_dca2"], r["pred1"], r["pred2"]], gt, MAXDISP, 5.0,
+                          False) + model_loss([r["pred_dca3"], pred4], gt, mask)
+        loss.backward()
+    dt = time.time() - t0
+    frac = rows_q / (H_IMG // 4)
+    return {"value": round(frac / dt, 5), "unit": "cost-volumes/s", "cores": threads, "kind": "port",
+            "sample": f"{mode} on a {4 * rows_q}x{W_IMG} crop ({rows_q}/{H_IMG // 4} of the rows, full width, D={MAXDISP}), "
+                      f"1 iteration, {dt:.1f} s, scaled by the row fraction"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1, help="stereo pairs per GPU (weak scaling)")
+    ap.add_argument("--mode", choices=["fwdbwd", "fwd"], default="fwdbwd")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=34)
+    args = ap.parse_args()
+
+    from dcanet_amd.parallel import FlatGradBucket, init_from_env
+    rank, local, world = init_from_env()
+    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    m = build_model(device)
+    fL, fR, guid, gt = make_inputs(args.batch, rank, device)
+    if args.mode == "fwdbwd":
+        m.train()
+        fL.requires_grad_(); fR.requires_grad_()
+        params = hot_params(m)
+        bucket = FlatGradBucket(params)
+        opt = torch.optim.Adam(params, lr=1e-3, betas=(0.9, 0.999))
+        step = lambda: train_step(m, fL, fR, guid, gt, bucket, opt)
+    else:
+        m.eval()
+        step = lambda: eval_step(m, fL, fR, guid)
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        volumes = args.steps * args.batch * world
+        line = {
+            "metric": "cost-volumes/sec (fwd+bwd) at 544x960 D=192" if args.mode == "fwdbwd"
+            else "cost-volumes/sec (fwd only) at 544x960 D=192",
+            "value": round(volumes / dt, 4), "unit": "cost-volumes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "gwcnet_dca_g (GwcNet-G + 3 DCA blocks) hot path from 1/4-res features, "
+                                   "544x960 D=192, " + ("train step: fwd(all heads)+focal/model loss+bwd+allreduce+Adam"
+                                                        if args.mode == "fwdbwd" else "eval forward"),
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "mode": args.mode},
+        }
+        roof = kernel_roofline(device)
+        names = list(roof)
+        line["roofline"] = dict(roof[names[0]], kernel=names[0])
+        line["roofline_other"] = {n: roof[n] for n in names[1:]}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(m, args.mode, args.cpu_rows)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

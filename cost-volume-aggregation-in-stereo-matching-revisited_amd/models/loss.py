@@ -1,0 +1,43 @@
+"""Mirror of the reference's models/loss.py for the two losses main_dca.py:132-133 uses.
+
+Host-side PyTorch code (works on any device): it sits AFTER the hot path and is small
+next to it.  Vectorised restatement of StereoFocalLoss.loss_per_level / LaplaceDisp2Prob (loss.py:117-128,
+206-240) and model_loss (loss.py:6-14); quirks of the reference are reproduced, not fixed (the estimates
+handed in are already softmax outputs and get log_softmax-ed again; the mean runs over all pixels)."""
+import torch
+import torch.nn.functional as F
+
+
+def model_loss(disp_ests, disp_gt, mask):
+    """reference loss.py:6-14: 1.8*SmoothL1(est0[mask]) + 2.1*SmoothL1(est1[mask])"""
+    weights = [1.8, 2.1]
+    assert len(weights) == len(disp_ests)
+    return sum(w * F.smooth_l1_loss(est[mask], disp_gt[mask], reduction="mean") for est, w in zip(disp_ests, weights))
+
+
+def _focal_level(est, gt, maxdisp, focal_coefficient, sparse):
+    N, C, H, W = est.shape
+    gt = gt.view(gt.shape[0], 1, gt.shape[-2], gt.shape[-1]) if gt.dim() != 4 else gt
+    scale = 1.0
+    sgt = gt
+    if gt.shape[-2] != H or gt.shape[-1] != W:
+        scale = gt.shape[-1] / (W * 1.0)
+        pool = F.adaptive_max_pool2d if sparse else F.adaptive_avg_pool2d
+        sgt = pool(gt / scale, (H, W))
+    nd = int(maxdisp / scale)
+    mask = ((sgt > 0) & (sgt < nd)).to(est.dtype)
+    mgt = sgt * mask
+    inner = ((mgt > 0) & (mgt < nd - 1)).to(est.dtype)          # Disp2Prob.getProb, loss.py:87-90
+    index = torch.arange(0, nd, dtype=est.dtype, device=est.device).view(1, nd, 1, 1)
+    prob = F.softmax(-torch.abs(index - mgt * inner), dim=1) * inner + 1e-40
+    prob = prob * (mask.sum() >= 1.0).to(est.dtype)            # "no valid point" -> zero target (loss.py:224-227)
+    logp = F.log_softmax(est, dim=1)
+    weight = (1.0 - prob).pow(-focal_coefficient)
+    return -((prob * logp) * weight * mask).sum(dim=1, keepdim=True).mean()
+
+
+def focal_loss(disp_ests, disp_gt, maxdisp, focal_coefficient, sparse):
+    """reference loss.py:16-24 (weights [0.5,0.7,1.0,1.2,1.5], silently truncating like zip does)."""
+    weights = [0.5, 0.7, 1.0, 1.2, 1.5]
+    return sum(w * _focal_level(est, disp_gt, maxdisp, focal_coefficient, sparse)
+               for est, w in zip(disp_ests, weights))

@@ -1,0 +1,59 @@
+"""Batch data-parallel helper for the DCANet training step: one process per GPU, the batch sharded on
+dim 0, ONE collective per step -- an all-reduce (sum, then / world) of a flat fp32 gradient bucket over
+RCCL/xGMI (backend "nccl" on ROCm) -- then the optimizer runs locally and identically on every rank.
+
+MI355X-first replacement of the reference's `nn.DataParallel` (main_dca.py:54, train_kitti.py:74): no
+per-step parameter broadcast, no scatter/gather through device 0.  BatchNorm statistics stay per replica,
+exactly as plain nn.BatchNorm3d under DataParallel behaves in the reference."""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run); returns (rank, local, world)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+class FlatGradBucket:
+    """Owns one contiguous fp32 buffer; parameter .grad tensors are views into it, so the all-reduce needs
+    no gather/scatter copies (18.3 MB for GwcNet-G: one message per step)."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        assert self.params, "no trainable parameters"
+        dev = self.params[0].device
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(self.numel, device=dev, dtype=torch.float32)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce_mean(self):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.div_(dist.get_world_size())
+
+
+def shard_batch(t: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    """dim-0 shard of a global batch (B must divide by world)."""
+    assert t.shape[0] % world == 0, "global batch must be divisible by the number of ranks"
+    per = t.shape[0] // world
+    return t[rank * per:(rank + 1) * per]

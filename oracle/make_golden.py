@@ -214,6 +214,21 @@ def gen_hot_path():
                 npz(stem, pred4_q=pred4, prob_volume2=prob2, gfL=g[0][:, ::16], gfR=g[1][:, ::16])
 
 
+def gen_losses():
+    import models.loss as ref_loss
+    gt = torch.rand(2, 1, 32, 64, generator=torch.Generator().manual_seed(7)) * 40.0 - 2.0   # some invalid (<0, >=32)
+    ests = [torch.softmax(seeded_tensor(f"loss.e{i}", (2, 8, 8, 16)), 1).requires_grad_() for i in range(5)]
+    fl = ref_loss.focal_loss(ests, gt, 32, 5.0, False)
+    fls = ref_loss.focal_loss(ests, gt, 32, 5.0, True)
+    g = torch.autograd.grad(fl, ests)
+    d0 = (seeded_tensor("loss.d0", (2, 1, 32, 64)) * 3 + gt).requires_grad_()
+    d1 = (seeded_tensor("loss.d1", (2, 1, 32, 64)) * 0.3 + gt).requires_grad_()
+    mask = (gt < 32) & (gt > 0)
+    ml = ref_loss.model_loss([d0, d1], gt, mask)
+    gd = torch.autograd.grad(ml, [d0, d1])
+    npz("losses", gt=gt, focal=fl, focal_sparse=fls, gfocal0=g[0], gfocal4=g[4], model=ml, gd0=gd[0], gd1=gd[1])
+
+
 def gen_state_dict_keys():
     """Key names + shapes of the reference model's state dict (the on-disk checkpoint format, main_dca.py:58-61)."""
     import json
@@ -229,7 +244,7 @@ def gen_state_dict_keys():
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["volumes", "inject", "attention", "cva", "magg", "hot", "keys"]
+    which = sys.argv[1:] or ["volumes", "inject", "attention", "cva", "magg", "hot", "keys", "losses"]
     with torch.enable_grad():
         if "volumes" in which: gen_volumes()
         if "inject" in which: gen_context_inject()
@@ -238,3 +253,4 @@ if __name__ == "__main__":
         if "magg" in which: gen_multi_agg_hourglass()
         if "hot" in which: gen_hot_path()
         if "keys" in which: gen_state_dict_keys()
+        if "losses" in which: gen_losses()

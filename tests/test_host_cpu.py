@@ -78,3 +78,27 @@ def test_product_does_not_import_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src, os.path.join(dirpath, f)
+
+
+def test_losses_match_reference(golden=None):
+    """models/loss.py mirror vs the reference's focal_loss / model_loss (tests/golden/losses.npz)."""
+    import numpy as np
+    from oracle.seeded import seeded_tensor
+    from dcanet_amd.models.loss import focal_loss, model_loss
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "losses.npz")))
+    gt = torch.from_numpy(g["gt"])
+    ests = [torch.softmax(seeded_tensor(f"loss.e{i}", (2, 8, 8, 16)), 1).requires_grad_() for i in range(5)]
+    fl = focal_loss(ests, gt, 32, 5.0, False)
+    assert abs(fl.item() - float(g["focal"])) < 1e-5 * max(1, abs(float(g["focal"])))
+    assert abs(focal_loss(ests, gt, 32, 5.0, True).item() - float(g["focal_sparse"])) < 1e-5 * max(1, abs(float(g["focal_sparse"])))
+    gr = torch.autograd.grad(fl, ests)
+    assert torch.allclose(gr[0], torch.from_numpy(g["gfocal0"]), atol=1e-6, rtol=1e-4)
+    assert torch.allclose(gr[4], torch.from_numpy(g["gfocal4"]), atol=1e-6, rtol=1e-4)
+    d0 = (seeded_tensor("loss.d0", (2, 1, 32, 64)) * 3 + gt).requires_grad_()
+    d1 = (seeded_tensor("loss.d1", (2, 1, 32, 64)) * 0.3 + gt).requires_grad_()
+    mask = (gt < 32) & (gt > 0)
+    ml = model_loss([d0, d1], gt, mask)
+    assert abs(ml.item() - float(g["model"])) < 1e-5 * max(1, abs(float(g["model"])))
+    gd = torch.autograd.grad(ml, [d0, d1])
+    assert torch.allclose(gd[0], torch.from_numpy(g["gd0"]), atol=1e-7, rtol=1e-4)
+    assert torch.allclose(gd[1], torch.from_numpy(g["gd1"]), atol=1e-7, rtol=1e-4)
