@@ -183,17 +183,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
   }
 }
 
-// backward: dq (registers), dk/dv accumulated in LDS across the 8 query-group threads of a pixel.
+// backward, two phases inside one workgroup (32 pixels x one head), no atomics:
+//  phase 1, thread = (pixel, query i): softmax statistics (m, 1/l), D_i = sum_j p_ij dP_ij, and dq_i;
+//           (m, 1/l, D) go to LDS next to the staged q / dout tiles.
+//  phase 2, thread = (pixel, key j):   dk_j = sum_i dS_ij q_i / sqrt(8), dv_j = sum_i p_ij dout_i in registers.
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                        const float* __restrict__ v, const float* __restrict__ dout,
                                                        float* __restrict__ dq, float* __restrict__ dk,
                                                        float* __restrict__ dv, int C, int n, long HW) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tile = 8 * n * 32;
-  float* ks = smem;
+  float* ks = smem;              // [8][n][32]
   float* vs = smem + tile;
-  float* dks = smem + 2 * tile;
-  float* dvs = smem + 3 * tile;
+  float* qs = smem + 2 * tile;   // pre-scaled by 1/sqrt(8)
+  float* gs = smem + 3 * tile;   // dout
+  float* st = smem + 4 * tile;   // [3][n][32]: m, 1/l, D
   const int tid = threadIdx.x, pl = tid & 31, qg = tid >> 5;
   const int head = blockIdx.y, b = blockIdx.z;
   const long pix0 = (long)blockIdx.x * 32, pix = pix0 + pl;
@@ -202,66 +206,89 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   for (int it = tid; it < tile; it += 256) {
     const int p = it & 31, cj = it >> 5;
     const bool ok = pix0 + p < HW;
-    ks[it] = ok ? k[hb + (long)cj * HW + pix0 + p] : 0.f;
-    vs[it] = ok ? v[hb + (long)cj * HW + pix0 + p] : 0.f;
-    dks[it] = 0.f;
-    dvs[it] = 0.f;
+    const long g = hb + (long)cj * HW + pix0 + p;
+    ks[it] = ok ? k[g] : 0.f;
+    vs[it] = ok ? v[g] : 0.f;
+    qs[it] = ok ? q[g] * scale : 0.f;
+    gs[it] = ok ? dout[g] : 0.f;
   }
   __syncthreads();
-  if (pix < HW) {
-    for (int i = qg; i < n; i += 8) {
-      float qv[8], go[8], dqv[8];
+  for (int i = qg; i < n; i += 8) {
+    float qv[8], go[8], dqv[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      qv[c] = qs[(c * n + i) * 32 + pl];
+      go[c] = gs[(c * n + i) * 32 + pl];
+      dqv[c] = 0.f;
+    }
+    float m = -INFINITY, l = 0.f, dnum = 0.f;
+    for (int j = 0; j < n; ++j) {
+      float s = 0.f, dp = 0.f;
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        qv[c] = q[hb + ((long)c * n + i) * HW + pix] * scale;
-        go[c] = dout[hb + ((long)c * n + i) * HW + pix];
-        dqv[c] = 0.f;
+        s += qv[c] * ks[(c * n + j) * 32 + pl];
+        dp += go[c] * vs[(c * n + j) * 32 + pl];
       }
-      // pass 1: softmax statistics and D = sum_j p_j dP_j (online)
-      float m = -INFINITY, l = 0.f, dnum = 0.f;
-      for (int j = 0; j < n; ++j) {
-        float s = 0.f, dp = 0.f;
+      const float mn = fmaxf(m, s);
+      const float corr = expf(m - mn), p = expf(s - mn);
+      l = l * corr + p;
+      dnum = dnum * corr + p * dp;
+      m = mn;
+    }
+    const float inv = 1.f / l, Dsum = dnum * inv;
+    st[(0 * n + i) * 32 + pl] = m;
+    st[(1 * n + i) * 32 + pl] = inv;
+    st[(2 * n + i) * 32 + pl] = Dsum;
+    for (int j = 0; j < n; ++j) {
+      float s = 0.f, dp = 0.f, kj[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          s += qv[c] * ks[(c * n + j) * 32 + pl];
-          dp += go[c] * vs[(c * n + j) * 32 + pl];
-        }
-        const float mn = fmaxf(m, s);
-        const float corr = expf(m - mn), p = expf(s - mn);
-        l = l * corr + p;
-        dnum = dnum * corr + p * dp;
-        m = mn;
+      for (int c = 0; c < 8; ++c) {
+        kj[c] = ks[(c * n + j) * 32 + pl];
+        s += qv[c] * kj[c];
+        dp += go[c] * vs[(c * n + j) * 32 + pl];
       }
-      const float inv = 1.f / l, Dsum = dnum * inv;
-      // pass 2: dS = p (dP - D); dq += dS k; dk += dS q; dv += p dout
-      for (int j = 0; j < n; ++j) {
-        float s = 0.f, dp = 0.f;
-        float kj[8];
+      const float ds = expf(s - m) * inv * (dp - Dsum);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          kj[c] = ks[(c * n + j) * 32 + pl];
-          s += qv[c] * kj[c];
-          dp += go[c] * vs[(c * n + j) * 32 + pl];
-        }
-        const float p = expf(s - m) * inv;
-        const float ds = p * (dp - Dsum);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          dqv[c] += ds * kj[c];
-          atomicAdd(&dks[(c * n + j) * 32 + pl], ds * qv[c]);   // qv already carries 1/sqrt(8)
-          atomicAdd(&dvs[(c * n + j) * 32 + pl], p * go[c]);
-        }
-      }
+      for (int c = 0; c < 8; ++c) dqv[c] += ds * kj[c];
+    }
+    if (pix < HW) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) dq[hb + ((long)c * n + i) * HW + pix] = dqv[c] * scale;
     }
   }
   __syncthreads();
-  for (int it = tid; it < tile; it += 256) {
-    const int p = it & 31, cj = it >> 5;
-    if (pix0 + p < HW) {
-      dk[hb + (long)cj * HW + pix0 + p] = dks[it];
-      dv[hb + (long)cj * HW + pix0 + p] = dvs[it];
+  for (int j = qg; j < n; j += 8) {
+    float kj[8], vj[8], dkj[8], dvj[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      kj[c] = ks[(c * n + j) * 32 + pl];
+      vj[c] = vs[(c * n + j) * 32 + pl];
+      dkj[c] = 0.f;
+      dvj[c] = 0.f;
+    }
+    for (int i = 0; i < n; ++i) {
+      float qv[8], go[8], s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        qv[c] = qs[(c * n + i) * 32 + pl];
+        go[c] = gs[(c * n + i) * 32 + pl];
+        s += qv[c] * kj[c];
+        dp += go[c] * vj[c];
+      }
+      const float p = expf(s - st[(0 * n + i) * 32 + pl]) * st[(1 * n + i) * 32 + pl];
+      const float ds = p * (dp - st[(2 * n + i) * 32 + pl]);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        dkj[c] += ds * qv[c];   // qv already carries 1/sqrt(8)
+        dvj[c] += p * go[c];
+      }
+    }
+    if (pix < HW) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        dk[hb + ((long)c * n + j) * HW + pix] = dkj[c];
+        dv[hb + ((long)c * n + j) * HW + pix] = dvj[c];
+      }
     }
   }
 }
@@ -324,7 +351,7 @@ extern "C" int dca_disp_attention_bwd(const float* q, const float* k, const floa
                                       float* dk, float* dv, int B, int C, int n, long HW, hipStream_t stream) {
   DCA_REQUIRE(q && k && v && dout && dq && dk && dv && B > 0 && C > 0 && C % 8 == 0 && n > 0 && n <= 32 && HW > 0);
   DCA_REQUIRE(C / 8 <= 65535 && B <= 65535);
-  const size_t lds = (size_t)4 * 8 * n * 32 * 4;
+  const size_t lds = (size_t)(4 * 8 + 3) * n * 32 * 4;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);

@@ -216,16 +216,27 @@ __global__ __launch_bounds__(256, 1) void wgrad1_kernel(WgArgs a) {
 }
 
 // dw[cy*s_cy + cx*s_cx + tap] = sum_blk part[((blk*nCT + ct)*K + tap)*1024 + (cy%32)*32 + cx%32]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nblk, int nCxT,
-                                    int nCT, int K, int Cy, int Cx, long s_cy, long s_cx) {
-  const int total = Cy * Cx * K;
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    const int tap = idx % K, cx = (idx / K) % Cx, cy = idx / (K * Cx);
-    const int ct = (cy >> 5) * nCxT + (cx >> 5);
-    const float* p = part + ((long)ct * K + tap) * 1024 + (cy & 31) * 32 + (cx & 31);
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += p[(long)b * nCT * K * 1024];
-    dw[cy * s_cy + cx * s_cx + tap] = s;
+// Threads walk the slab in memory order (coalesced); 4 thread groups split the slabs and meet in LDS, always
+// summing in the same order (deterministic).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                           int nblk, int nCxT, int nCT, int K, int Cy, int Cx,
+                                                           long s_cy, long s_cx) {
+  __shared__ float red[4][64];
+  const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long slab_elems = (long)nCT * K * 1024;
+  const long idx = (long)blockIdx.x * 64 + e;   // element inside one worker's slab set
+  float s = 0.f;
+  if (idx < slab_elems)
+    for (int b = g; b < nblk; b += 4) s += part[(long)b * slab_elems + idx];
+  red[g][e] = s;
+  __syncthreads();
+  if (g == 0 && idx < slab_elems) {
+    const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    const int cxl = idx & 31, cyl = (idx >> 5) & 31;
+    const long t = idx >> 10;
+    const int tap = t % K, ct = t / K;
+    const int cy = (ct / nCxT) * 32 + cyl, cx = (ct % nCxT) * 32 + cxl;
+    if (cy < Cy && cx < Cx) dw[cy * s_cy + cx * s_cx + tap] = v;
   }
 }
 
@@ -303,7 +314,7 @@ extern "C" int dca_conv3d_wgrad(const float* x, const float* dy, float* part, fl
   }
   int st = dca_launch_status();
   if (st) return st;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((long)Cy * Cx * K, 256)), dim3(256), 0, stream, part, dw, nblk,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((long)nCT * K * 1024, 64)), dim3(256), 0, stream, part, dw, nblk,
                      a.nCxT, nCT, K, Cy, Cx, s_cy, s_cx);
   return dca_launch_status();
 }

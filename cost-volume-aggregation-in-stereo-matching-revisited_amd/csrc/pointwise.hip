@@ -118,20 +118,37 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ res_pre,
                                                             const float* __restrict__ stats,
                                                             double* __restrict__ part, int N, int C, long S,
-                                                            int nchunk, long chunk_len, float slope) {
+                                                            int nchunk, long chunk_len, float slope, int vec) {
   const int c = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
   const long s0 = ch * chunk_len, s1 = min(S, s0 + chunk_len);
   const float mean = stats[c], invstd = stats[C + c], sc = stats[2 * C + c], sh = stats[3 * C + c];
   float a0 = 0.f, a1 = 0.f;
   for (int n = 0; n < N; ++n) {
     const long base = ((long)n * C + c) * S;
-    for (long i = s0 + tid; i < s1; i += 256) {
-      const float yv = y[base + i];
-      float u = yv * sc + sh;
-      if (res_pre) u += res_pre[base + i];
-      const float g = dz[base + i] * (u > 0.f ? 1.f : slope);
-      a0 += g;
-      a1 += g * (yv - mean) * invstd;
+    if (vec) {
+      for (long i = s0 + 4 * tid; i < s1; i += 1024) {
+        const float4 yv = *(const float4*)(y + base + i);
+        const float4 dv = *(const float4*)(dz + base + i);
+        float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (res_pre) rv = *(const float4*)(res_pre + base + i);
+        const float ys[4] = {yv.x, yv.y, yv.z, yv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w}, rs[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float u = ys[j] * sc + sh + rs[j];
+          const float g = ds[j] * (u > 0.f ? 1.f : slope);
+          a0 += g;
+          a1 += g * (ys[j] - mean) * invstd;
+        }
+      }
+    } else {
+      for (long i = s0 + tid; i < s1; i += 256) {
+        const float yv = y[base + i];
+        float u = yv * sc + sh;
+        if (res_pre) u += res_pre[base + i];
+        const float g = dz[base + i] * (u > 0.f ? 1.f : slope);
+        a0 += g;
+        a1 += g * (yv - mean) * invstd;
+      }
     }
   }
   double d0 = wave_sum_d((double)a0), d1 = wave_sum_d((double)a1);
@@ -164,7 +181,29 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nchu
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ y,
                                     const float* __restrict__ res_pre, const float* __restrict__ stats,
                                     const float* __restrict__ dgb, float* __restrict__ dy, float* __restrict__ g_out,
-                                    int C, long S, long total, float slope, int training) {
+                                    int C, long S, long total, float slope, int training, int vec) {
+  if (vec) {
+    const long total4 = total >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+      const int c = (int)((i * 4 / S) % C);
+      const float mean = stats[c], invstd = stats[C + c], sc = stats[2 * C + c], sh = stats[3 * C + c];
+      const float k1 = training ? dgb[2 * C + c] : 0.f, k2 = training ? dgb[3 * C + c] * invstd : 0.f;
+      const float4 yv = ((const float4*)y)[i], dv = ((const float4*)dz)[i];
+      float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (res_pre) rv = ((const float4*)res_pre)[i];
+      const float ys[4] = {yv.x, yv.y, yv.z, yv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w}, rs[4] = {rv.x, rv.y, rv.z, rv.w};
+      float o[4], g[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float u = ys[j] * sc + sh + rs[j];
+        g[j] = ds[j] * (u > 0.f ? 1.f : slope);
+        o[j] = (g[j] - k1 - (ys[j] - mean) * k2) * sc;
+      }
+      ((float4*)dy)[i] = make_float4(o[0], o[1], o[2], o[3]);
+      if (g_out) ((float4*)g_out)[i] = make_float4(g[0], g[1], g[2], g[3]);
+    }
+    return;
+  }
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)((i / S) % C);
     const float mean = stats[c], invstd = stats[C + c], sc = stats[2 * C + c], sh = stats[3 * C + c];
@@ -316,6 +355,84 @@ __global__ void trilinear_bwd_kernel(const float* __restrict__ gy, float* __rest
   }
 }
 
+// x2 up-sampling, specialised: per dim o=2m -> 0.25 x[m-1] + 0.75 x[m] (m=0: x[0]); o=2m+1 -> 0.75 x[m] + 0.25 x[m+1]
+// (m=n-1: x[n-1]).  One thread per coarse cell writes its 2x2x2 outputs (two float2 stores per row pair); grid
+// (W tiles, H, NC*D) so no 64-bit div/mod chains.
+__global__ __launch_bounds__(256) void trilinear_up2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                int Di, int Hi, int Wi) {
+  const int mw = blockIdx.x * 256 + threadIdx.x, mh = blockIdx.y;
+  const int md = blockIdx.z % Di;
+  const long nc = blockIdx.z / Di;
+  if (mw >= Wi) return;
+  const float* p = x + nc * Di * Hi * Wi;
+  const int dm = max(md - 1, 0), dp = min(md + 1, Di - 1), hm = max(mh - 1, 0), hp = min(mh + 1, Hi - 1);
+  const int wm = max(mw - 1, 0), wp = min(mw + 1, Wi - 1);
+  // rows: (d in {dm, md, dp}) x (h in {hm, mh, hp}), each reduced along w to the two outputs (2mw, 2mw+1)
+  float r0[3][3], r1[3][3];
+  const int ds[3] = {dm, md, dp}, hs[3] = {hm, mh, hp};
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const float* row = p + ((long)ds[a] * Hi + hs[b]) * Wi;
+      const float xm = row[wm], x0 = row[mw], xp = row[wp];
+      r0[a][b] = 0.25f * xm + 0.75f * x0;
+      r1[a][b] = 0.75f * x0 + 0.25f * xp;
+    }
+  const int Ho = 2 * Hi, Wo = 2 * Wi;
+  float* q = y + nc * (2L * Di) * Ho * Wo;
+#pragma unroll
+  for (int pd = 0; pd < 2; ++pd)
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+      // along d: pd=0 -> .25*[dm] + .75*[md]; pd=1 -> .75*[md] + .25*[dp]; same along h
+      const int a0 = pd ? 1 : 0, a1 = pd ? 2 : 1, b0 = ph ? 1 : 0, b1 = ph ? 2 : 1;
+      const float wa0 = pd ? 0.75f : 0.25f, wa1 = pd ? 0.25f : 0.75f, wb0 = ph ? 0.75f : 0.25f, wb1 = ph ? 0.25f : 0.75f;
+      float2 o;
+      o.x = wa0 * (wb0 * r0[a0][b0] + wb1 * r0[a0][b1]) + wa1 * (wb0 * r0[a1][b0] + wb1 * r0[a1][b1]);
+      o.y = wa0 * (wb0 * r1[a0][b0] + wb1 * r1[a0][b1]) + wa1 * (wb0 * r1[a1][b0] + wb1 * r1[a1][b1]);
+      *(float2*)(q + ((long)(2 * md + pd) * Ho + 2 * mh + ph) * Wo + 2 * mw) = o;
+    }
+}
+
+// per-dim backward weights of the x2 up-sampling: input i gets outputs 2i-1, 2i, 2i+1, 2i+2 with weights
+// (.25, .75, .75, .25); the clamped ends fold the missing neighbour's weight into the edge sample.
+__device__ __forceinline__ void up2_bwd_w(int i, int n, float w[4]) {
+  w[0] = (i > 0) ? 0.25f : 0.f;
+  w[1] = (i > 0) ? 0.75f : 1.0f;
+  w[2] = (i < n - 1) ? 0.75f : 1.0f;
+  w[3] = (i < n - 1) ? 0.25f : 0.f;
+}
+
+__global__ __launch_bounds__(256) void trilinear_up2_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
+                                                                int Di, int Hi, int Wi) {
+  const int w = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y;
+  const int d = blockIdx.z % Di;
+  const long nc = blockIdx.z / Di;
+  if (w >= Wi) return;
+  const int Ho = 2 * Hi, Wo = 2 * Wi;
+  const float* p = gy + nc * (2L * Di) * Ho * Wo;
+  float wd[4], wh[4], ww[4];
+  up2_bwd_w(d, Di, wd); up2_bwd_w(h, Hi, wh); up2_bwd_w(w, Wi, ww);
+  float acc = 0.f;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int od = 2 * d - 1 + a;
+    if (wd[a] == 0.f) continue;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int oh = 2 * h - 1 + b;
+      if (wh[b] == 0.f) continue;
+      const float* row = p + ((long)od * Ho + oh) * Wo + 2 * w;
+      float r = ww[1] * row[0] + ww[2] * row[1];
+      if (ww[0] != 0.f) r += ww[0] * row[-1];
+      if (ww[3] != 0.f) r += ww[3] * row[2];
+      acc += wd[a] * wh[b] * r;
+    }
+  }
+  gx[((nc * Di + d) * Hi + h) * Wi + w] = acc;
+}
+
 static int ew_grid(long total) {
   long g = (total + 255) / 256;
   return (int)(g < 8192 ? (g > 0 ? g : 1) : 8192);
@@ -371,13 +488,15 @@ extern "C" int dca_bn_backward(const float* dz, const float* y, const float* res
   DCA_REQUIRE(dz && y && stats && part && dgb && dy && N > 0 && C > 0 && S > 0 && C <= 65535);
   int nchunk; long len;
   chunking(S, C, &nchunk, &len);
+  const uintptr_t al = (uintptr_t)dz | (uintptr_t)y | (uintptr_t)res_pre | (uintptr_t)dy | (uintptr_t)g_out;
+  const int vec = (S % 4 == 0) && ((al & 15) == 0);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, nchunk), dim3(256), 0, stream, dz, y, res_pre, stats, part, N, C, S,
-                     nchunk, len, slope);
+                     nchunk, len, slope, vec);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, part, nchunk,
                      (double)N * (double)S, dgb, C);
   const long total = (long)N * C * S;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, dz, y, res_pre, stats, dgb, dy,
-                     g_out, C, S, total, slope, training);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(vec ? total / 4 : total)), dim3(256), 0, stream, dz, y, res_pre,
+                     stats, dgb, dy, g_out, C, S, total, slope, training, vec);
   return dca_launch_status();
 }
 
@@ -400,6 +519,11 @@ extern "C" int dca_avgpool3d_bwd(const float* gy, float* gx, long NC, int Di, in
 extern "C" int dca_trilinear_fwd(const float* x, float* y, long NC, int Di, int Hi, int Wi, int scale,
                                  hipStream_t stream) {
   DCA_REQUIRE(x && y && NC > 0 && Di > 0 && Hi > 0 && Wi > 0 && scale >= 1);
+  if (scale == 2 && Hi <= 65535 && NC * Di <= 65535 && (((uintptr_t)y & 7) == 0)) {
+    hipLaunchKernelGGL(trilinear_up2_fwd_kernel, dim3(cdiv(Wi, 256), Hi, (unsigned)(NC * Di)), dim3(256), 0, stream, x, y,
+                       Di, Hi, Wi);
+    return dca_launch_status();
+  }
   const long total = NC * Di * Hi * Wi * scale * scale * scale;
   hipLaunchKernelGGL(trilinear_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, x, y, NC, Di, Hi, Wi, scale);
   return dca_launch_status();
@@ -408,6 +532,11 @@ extern "C" int dca_trilinear_fwd(const float* x, float* y, long NC, int Di, int 
 extern "C" int dca_trilinear_bwd(const float* gy, float* gx, long NC, int Di, int Hi, int Wi, int scale,
                                  hipStream_t stream) {
   DCA_REQUIRE(gy && gx && NC > 0 && Di > 0 && Hi > 0 && Wi > 0 && scale >= 1);
+  if (scale == 2 && Hi <= 65535 && NC * Di <= 65535) {
+    hipLaunchKernelGGL(trilinear_up2_bwd_kernel, dim3(cdiv(Wi, 256), Hi, (unsigned)(NC * Di)), dim3(256), 0, stream, gy, gx,
+                       Di, Hi, Wi);
+    return dca_launch_status();
+  }
   hipLaunchKernelGGL(trilinear_bwd_kernel, dim3(ew_grid(NC * Di * Hi * Wi)), dim3(256), 0, stream, gy, gx, NC, Di, Hi,
                      Wi, scale);
   return dca_launch_status();

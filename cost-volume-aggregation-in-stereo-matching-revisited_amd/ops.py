@@ -224,6 +224,40 @@ def _wgrad(x, dy, dw_view_ptr_tensor, dst_offset, Cx, Cy, ksize, stride, s_cy, s
                                s_cy, s_cx, _stream()), "dca_conv3d_wgrad")
 
 
+class _Conv3dC1(torch.autograd.Function):
+    """nn.Conv3d(C, 1, 3, padding=1, bias=False): the logit heads (VALU/bandwidth kernels, no MFMA waste)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x, weight = _req(x, "conv3d"), _req(weight, "conv3d.weight")
+        N, C, D, H, W = x.shape
+        y = torch.empty((N, 1, D, H, W), device=x.device, dtype=torch.float32)
+        with torch.cuda.device_of(x):
+            _chk(_L().dca_conv3d_c1_fwd(_ptr(x), _ptr(weight), _ptr(y), N, C, D, H, W, _stream()), "dca_conv3d_c1_fwd")
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = _req(dy, "conv3d.backward")
+        N, C, D, H, W = x.shape
+        gx = gw = None
+        lib = _L()
+        with torch.cuda.device_of(x):
+            if ctx.needs_input_grad[0]:
+                gx = torch.empty_like(x)
+                _chk(lib.dca_conv3d_c1_bwd_data(_ptr(dy), _ptr(weight), _ptr(gx), N, C, D, H, W, _stream()),
+                     "dca_conv3d_c1_bwd_data")
+            if ctx.needs_input_grad[1]:
+                gw = torch.empty_like(weight)
+                part = torch.empty((lib.dca_conv3d_c1_wgrad_workspace(N, C, D, H, W),), device=x.device,
+                                   dtype=torch.float32)
+                _chk(lib.dca_conv3d_c1_wgrad(_ptr(x), _ptr(dy), _ptr(part), _ptr(gw), N, C, D, H, W, _stream()),
+                     "dca_conv3d_c1_wgrad")
+        return gx, gw
+
+
 class _Conv3d(torch.autograd.Function):
     """Conv3d (k=3 pad=1 stride 1|2, or k=1) / ConvTranspose3d (k=3 s=2 p=1 op=1), bias=False.
     Optional second input x2 = implicit channel concat for the 1x1x1 `fuse` conv."""
@@ -294,6 +328,8 @@ class _Conv3d(torch.autograd.Function):
 
 
 def conv3d(x, weight, stride=1, transposed=False, x2=None):
+    if (not transposed and x2 is None and weight.shape[0] == 1 and weight.shape[2] == 3 and int(stride) == 1):
+        return _Conv3dC1.apply(x, weight)
     return _Conv3d.apply(x, x2, weight, int(stride), bool(transposed))
 
 

@@ -79,6 +79,17 @@ long dca_conv3d_wgrad_workspace(int N, int Cx, int Cy, int Do, int Ho, int Wo, i
 int dca_conv3d_wgrad(const float* x, const float* dy, float* part, float* dw, int N, int Cx, int Cy, int Di, int Hi,
                      int Wi, int Do, int Ho, int Wo, int ksize, int stride, long s_cy, long s_cx, hipStream_t stream);
 
+/* Single-output-channel 3x3x3 convolution (the logit heads: nn.Conv3d(32, 1, 3, padding=1, bias=False),
+ * models/gwcnet_dca_g.py:154-168 `classif*.2`, models/augment/cva.py:51-53 `classify.2`).  w is the PyTorch weight
+ * (1,C,3,3,3) as is.  fwd: x (N,C,D,H,W) -> y (N,1,D,H,W); bwd_data: dy (N,1,..) -> dx (N,C,..);
+ * wgrad: dw (1,C,27) with `part` = dca_conv3d_c1_wgrad_workspace(...) floats of scratch. */
+int dca_conv3d_c1_fwd(const float* x, const float* w, float* y, int N, int C, int D, int H, int W, hipStream_t stream);
+int dca_conv3d_c1_bwd_data(const float* dy, const float* w, float* dx, int N, int C, int D, int H, int W,
+                           hipStream_t stream);
+long dca_conv3d_c1_wgrad_workspace(int N, int C, int D, int H, int W);
+int dca_conv3d_c1_wgrad(const float* x, const float* dy, float* part, float* dw, int N, int C, int D, int H, int W,
+                        hipStream_t stream);
+
 /* ---- BatchNorm3d + activation + residual -------------------------------------------------------------
  * nn.BatchNorm3d defaults (eps 1e-5, momentum 0.1) as used by convbn_3d, models/submodule.py:121-124.
  * dca_bn_stats:    part[(c*nchunk+i)*2+{0,1}] = partial (sum, sum of squares) in double;
