@@ -59,7 +59,17 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(WgArgs a) {
   const float* xb = xs + l31 * XP + 3 + half * S;
   const float* yb = ys + l31 * YP + half;
 
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+  // Software pipeline (aligned case): the NEXT tile's global loads are issued into registers before the MFMA
+  // loop of the current tile and written to LDS after it, so HBM/L2 latency hides under the matrix work
+  // (one wave per SIMD here: 512 registers are available, the prefetch set is ~130).
+  constexpr int ROWS = 32 * ID * IH;
+  constexpr int QPR = 8 * S, NH = (S == 1) ? 2 : 1;
+  constexpr int KX = (ROWS * QPR + 255) / 256, KH = (ROWS * NH + 255) / 256, KY = (32 * NR * 8 + 255) / 256;
+  float4 rx[KX], ry[KY];
+  float rh[KH];
+  const bool pipelined = a.vecx && a.vecy;
+
+  auto load_regs = [&](int tile) {
     int t = tile;
     const int tw = t % a.nTW; t /= a.nTW;
     const int th = t % a.nTH; t /= a.nTH;
@@ -67,33 +77,81 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(WgArgs a) {
     const int n = t / a.nTD;
     const int d0 = td * TD, h0 = th * TH, w0 = tw * 32;
     const int di0 = d0 * S - 1, hi0 = h0 * S - 1, wi0 = w0 * S - 1;
-    __syncthreads();
-    // ---- x halo tile
-    constexpr int ROWS = 32 * ID * IH;
-    if (a.vecx) {
-      constexpr int QPR = 8 * S;
-      for (int it = tid; it < ROWS * QPR; it += 256) {
+#pragma unroll
+    for (int k = 0; k < KX; ++k) {
+      const int it = tid + 256 * k;
+      const int row = it / QPR, q = it % QPR;
+      const int c = row / (ID * IH), rem = row % (ID * IH), id = rem / IH, ih = rem % IH;
+      const int ci = cx0 + c, di = di0 + id, hi = hi0 + ih, wi = wi0 + 1 + 4 * q;
+      rx[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (it < ROWS * QPR && ci < a.Cx && (unsigned)di < (unsigned)a.Di && (unsigned)hi < (unsigned)a.Hi && wi < a.Wi)
+        rx[k] = *(const float4*)(a.x + ((((long)n * a.Cx + ci) * a.Di + di) * a.Hi + hi) * a.Wi + wi);
+    }
+#pragma unroll
+    for (int k = 0; k < KH; ++k) {
+      const int it = tid + 256 * k;
+      const int row = it / NH, j = (it % NH) ? (IW - 1) : 0;
+      const int c = row / (ID * IH), rem = row % (ID * IH), id = rem / IH, ih = rem % IH;
+      const int ci = cx0 + c, di = di0 + id, hi = hi0 + ih, wi = wi0 + j;
+      rh[k] = 0.f;
+      if (it < ROWS * NH && ci < a.Cx && (unsigned)di < (unsigned)a.Di && (unsigned)hi < (unsigned)a.Hi &&
+          (unsigned)wi < (unsigned)a.Wi)
+        rh[k] = a.x[((((long)n * a.Cx + ci) * a.Di + di) * a.Hi + hi) * a.Wi + wi];
+    }
+#pragma unroll
+    for (int k = 0; k < KY; ++k) {
+      const int it = tid + 256 * k;
+      const int q = it & 7, row = (it >> 3) % NR, c = it / (8 * NR);
+      const int co = cy0 + c, d = d0 + row / TH, h = h0 + row % TH, w = w0 + 4 * q;
+      ry[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (it < 32 * NR * 8 && co < a.Cy && d < a.Do && h < a.Ho && w < a.Wo)
+        ry[k] = *(const float4*)(a.dy + ((((long)n * a.Cy + co) * a.Do + d) * a.Ho + h) * a.Wo + w);
+    }
+  };
+  auto store_regs = [&]() {
+#pragma unroll
+    for (int k = 0; k < KX; ++k) {
+      const int it = tid + 256 * k;
+      if (it < ROWS * QPR) {
         const int row = it / QPR, q = it % QPR;
-        const int c = row / (ID * IH), rem = row % (ID * IH), id = rem / IH, ih = rem % IH;
-        const int ci = cx0 + c, di = di0 + id, hi = hi0 + ih, wi = wi0 + 1 + 4 * q;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ci < a.Cx && (unsigned)di < (unsigned)a.Di && (unsigned)hi < (unsigned)a.Hi && wi < a.Wi)
-          v = *(const float4*)(a.x + ((((long)n * a.Cx + ci) * a.Di + di) * a.Hi + hi) * a.Wi + wi);
+        const int c = row / (ID * IH), rem = row % (ID * IH);
         float* dst = xs + c * XP + rem * IWP + 4 + 4 * q;
-        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        dst[0] = rx[k].x; dst[1] = rx[k].y; dst[2] = rx[k].z; dst[3] = rx[k].w;
       }
-      constexpr int NH = (S == 1) ? 2 : 1;
-      for (int it = tid; it < ROWS * NH; it += 256) {
+    }
+#pragma unroll
+    for (int k = 0; k < KH; ++k) {
+      const int it = tid + 256 * k;
+      if (it < ROWS * NH) {
         const int row = it / NH, j = (it % NH) ? (IW - 1) : 0;
-        const int c = row / (ID * IH), rem = row % (ID * IH), id = rem / IH, ih = rem % IH;
-        const int ci = cx0 + c, di = di0 + id, hi = hi0 + ih, wi = wi0 + j;
-        float v = 0.f;
-        if (ci < a.Cx && (unsigned)di < (unsigned)a.Di && (unsigned)hi < (unsigned)a.Hi &&
-            (unsigned)wi < (unsigned)a.Wi)
-          v = a.x[((((long)n * a.Cx + ci) * a.Di + di) * a.Hi + hi) * a.Wi + wi];
-        xs[c * XP + rem * IWP + 3 + j] = v;
+        const int c = row / (ID * IH), rem = row % (ID * IH);
+        xs[c * XP + rem * IWP + 3 + j] = rh[k];
       }
+    }
+#pragma unroll
+    for (int k = 0; k < KY; ++k) {
+      const int it = tid + 256 * k;
+      if (it < 32 * NR * 8) {
+        const int q = it & 7, row = (it >> 3) % NR, c = it / (8 * NR);
+        float* dst = ys + c * YP + row * 32 + 4 * q;
+        dst[0] = ry[k].x; dst[1] = ry[k].y; dst[2] = ry[k].z; dst[3] = ry[k].w;
+      }
+    }
+  };
+
+  if (pipelined) load_regs(blockIdx.x);
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    __syncthreads();
+    if (pipelined) {
+      store_regs();
     } else {
+      int t = tile;
+      const int tw = t % a.nTW; t /= a.nTW;
+      const int th = t % a.nTH; t /= a.nTH;
+      const int td = t % a.nTD;
+      const int n = t / a.nTD;
+      const int d0 = td * TD, h0 = th * TH, w0 = tw * 32;
+      const int di0 = d0 * S - 1, hi0 = h0 * S - 1, wi0 = w0 * S - 1;
       for (int it = tid; it < ROWS * IW; it += 256) {
         const int row = it / IW, j = it % IW;
         const int c = row / (ID * IH), rem = row % (ID * IH), id = rem / IH, ih = rem % IH;
@@ -104,19 +162,6 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(WgArgs a) {
           v = a.x[((((long)n * a.Cx + ci) * a.Di + di) * a.Hi + hi) * a.Wi + wi];
         xs[c * XP + rem * IWP + 3 + j] = v;
       }
-    }
-    // ---- dy tile
-    if (a.vecy) {
-      for (int it = tid; it < 32 * NR * 8; it += 256) {
-        const int q = it & 7, row = (it >> 3) % NR, c = it / (8 * NR);
-        const int co = cy0 + c, d = d0 + row / TH, h = h0 + row % TH, w = w0 + 4 * q;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (co < a.Cy && d < a.Do && h < a.Ho && w < a.Wo)
-          v = *(const float4*)(a.dy + ((((long)n * a.Cy + co) * a.Do + d) * a.Ho + h) * a.Wo + w);
-        float* dst = ys + c * YP + row * 32 + 4 * q;
-        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-      }
-    } else {
       for (int it = tid; it < 32 * NV; it += 256) {
         const int wl = it & 31, row = (it >> 5) % NR, c = it / NV;
         const int co = cy0 + c, d = d0 + row / TH, h = h0 + row % TH, w = w0 + wl;
@@ -127,6 +172,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(WgArgs a) {
       }
     }
     __syncthreads();
+    if (pipelined && tile + (int)gridDim.x < a.ntiles) load_regs(tile + gridDim.x);
     // ---- contraction over the tile's voxels, two per MFMA
 #pragma unroll 1
     for (int row = 0; row < NR; ++row) {
