@@ -39,28 +39,39 @@ __device__ __forceinline__ float epilogue(const ConvArgs& a, float v, int co, lo
 }
 
 // ---------------------------------------------------------------------------------------------
-// 3x3x3, pad 1, stride S.  Block = 4 waves; output tile TD x TH x 32(W); each wave owns
-// NT = TD*TH/4 rows of 32 voxels and all CT*32 output channels.
+// 3x3x3, pad 1, stride S.  Block = 4 waves; output tile TD x TH x TW; an MFMA column tile is 32 voxels =
+// (32/TW) consecutive H rows x TW consecutive W positions (TW = 32: one row; TW = 16: two rows, which lets
+// W = 240 tile with no wasted lanes).  Each wave owns NT = TD*TH*TW/128 such tiles and all CT*32 output
+// channels.  The host picks (TD, TH, TW) per problem to minimise padding waste and grid tail.
+// Aligned inputs (VEC) run a software pipeline: the next channel chunk's global loads (input halo tile and
+// weights) are issued into registers before the MFMA loop of the current chunk and written to LDS after it.
 // ---------------------------------------------------------------------------------------------
-template <int S, int CT, int CK, int TD, int TH, bool VEC>
+template <int S, int CT, int CK, int TD, int TH, int TW, bool VEC>
 __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
-  constexpr int NT = TD * TH / 4;
-  constexpr int ID = (TD - 1) * S + 3, IH = (TH - 1) * S + 3, IW = 31 * S + 3;
-  constexpr int IWP = (S == 1) ? 40 : 68;
+  static_assert(TW == 32 || (TW == 16 && S == 1), "tile width");
+  constexpr int RPT = 32 / TW;                 // H rows per MFMA tile
+  constexpr int NT = TD * TH / RPT / 4;        // MFMA tiles per wave
+  static_assert(NT * 4 * RPT == TD * TH, "tile shape");
+  constexpr int ID = (TD - 1) * S + 3, IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
+  constexpr int IWP = ((3 + IW + 3) / 4) * 4;  // interior starts at column 4 (16-byte aligned)
   constexpr int CO = CT * 32;
   constexpr int ROWS = CK * ID * IH;
   constexpr int IN_ELEMS = ROWS * IWP;
+  constexpr int QPR = TW * S / 4;              // float4 per interior row
+  constexpr int NH = (S == 1) ? 2 : 1;         // halo scalars per row
+  constexpr int WQ = CK * CO / 4;              // weight float4 per tap
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* in_lds = smem;
   float* w_lds = smem + IN_ELEMS;
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  const int wl = l31 & (TW - 1), hsel = l31 / TW;
   int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int tw = bid % a.nTW; bid /= a.nTW;
   const int th = bid % a.nTH; bid /= a.nTH;
   const int td = bid % a.nTD;
   const int n = bid / a.nTD;
-  const int d0 = td * TD, h0 = th * TH, w0 = tw * 32;
+  const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
   const int di0 = d0 * S - 1, hi0 = h0 * S - 1, wi0 = w0 * S - 1;
 
   f32x16 acc[NT][CT];
@@ -74,34 +85,66 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
   int boff[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int r = wv * NT + t, dl = r / TH, hl = r % TH;
-    boff[t] = ((half * ID + dl * S) * IH + hl * S) * IWP + 3 + l31 * S;
+    const int r = (wv * NT + t) * RPT + hsel, dl = r / TH, hl = r % TH;
+    boff[t] = ((half * ID + dl * S) * IH + hl * S) * IWP + 3 + wl * S;
   }
 
+  constexpr int KX = (ROWS * QPR + 255) / 256, KH = (ROWS * NH + 255) / 256, KW = (27 * WQ + 255) / 256;
+  float4 rx[VEC ? KX : 1], rw[VEC ? KW : 1];
+  float rh[VEC ? KH : 1];
+
+  auto load_regs = [&](int ci0) {
+#pragma unroll
+    for (int k = 0; k < KX; ++k) {
+      const int it = tid + 256 * k;
+      const int row = it / QPR, q = it % QPR;
+      const int c = row / (ID * IH), rem = row % (ID * IH), id = rem / IH, ih = rem % IH;
+      const int ci = ci0 + c, di = di0 + id, hi = hi0 + ih, wi = wi0 + 1 + 4 * q;
+      rx[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (it < ROWS * QPR && ci < a.Cin && (unsigned)di < (unsigned)a.Di && (unsigned)hi < (unsigned)a.Hi && wi < a.Wi)
+        rx[k] = *(const float4*)(a.x + ((((long)n * a.Cin + ci) * a.Di + di) * a.Hi + hi) * a.Wi + wi);
+    }
+#pragma unroll
+    for (int k = 0; k < KH; ++k) {
+      const int it = tid + 256 * k;
+      const int row = it / NH, j = (it % NH) ? (IW - 1) : 0;
+      const int c = row / (ID * IH), rem = row % (ID * IH), id = rem / IH, ih = rem % IH;
+      const int ci = ci0 + c, di = di0 + id, hi = hi0 + ih, wi = wi0 + j;
+      rh[k] = 0.f;
+      if (it < ROWS * NH && ci < a.Cin && (unsigned)di < (unsigned)a.Di && (unsigned)hi < (unsigned)a.Hi &&
+          (unsigned)wi < (unsigned)a.Wi)
+        rh[k] = a.x[((((long)n * a.Cin + ci) * a.Di + di) * a.Hi + hi) * a.Wi + wi];
+    }
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+      const int it = tid + 256 * k;
+      const int tap = it / WQ, q = it % WQ;
+      if (it < 27 * WQ) rw[k] = *(const float4*)(a.wt + ((long)tap * a.CinPad + ci0) * CO + 4 * q);
+    }
+  };
+  auto store_regs = [&]() {
+#pragma unroll
+    for (int k = 0; k < KX; ++k) {
+      const int it = tid + 256 * k;
+      if (it < ROWS * QPR) *(float4*)(in_lds + (it / QPR) * IWP + 4 + 4 * (it % QPR)) = rx[k];
+    }
+#pragma unroll
+    for (int k = 0; k < KH; ++k) {
+      const int it = tid + 256 * k;
+      if (it < ROWS * NH) in_lds[(it / NH) * IWP + 3 + ((it % NH) ? (IW - 1) : 0)] = rh[k];
+    }
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+      const int it = tid + 256 * k;
+      if (it < 27 * WQ) *(float4*)(w_lds + (it / WQ) * CK * CO + 4 * (it % WQ)) = rw[k];
+    }
+  };
+
+  if constexpr (VEC) load_regs(0);
   for (int ci0 = 0; ci0 < a.CinPad; ci0 += CK) {
     __syncthreads();
-    if (VEC) {
-      constexpr int QPR = 8 * S;
-      for (int it = tid; it < ROWS * QPR; it += 256) {
-        const int row = it / QPR, q = it % QPR;
-        const int c = row / (ID * IH), rem = row % (ID * IH), id = rem / IH, ih = rem % IH;
-        const int ci = ci0 + c, di = di0 + id, hi = hi0 + ih, wi = wi0 + 1 + 4 * q;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ci < a.Cin && (unsigned)di < (unsigned)a.Di && (unsigned)hi < (unsigned)a.Hi && wi < a.Wi)
-          v = *(const float4*)(a.x + ((((long)n * a.Cin + ci) * a.Di + di) * a.Hi + hi) * a.Wi + wi);
-        *(float4*)(in_lds + row * IWP + 4 + 4 * q) = v;
-      }
-      constexpr int NH = (S == 1) ? 2 : 1;
-      for (int it = tid; it < ROWS * NH; it += 256) {
-        const int row = it / NH, j = (it % NH) ? (IW - 1) : 0;
-        const int c = row / (ID * IH), rem = row % (ID * IH), id = rem / IH, ih = rem % IH;
-        const int ci = ci0 + c, di = di0 + id, hi = hi0 + ih, wi = wi0 + j;
-        float v = 0.f;
-        if (ci < a.Cin && (unsigned)di < (unsigned)a.Di && (unsigned)hi < (unsigned)a.Hi &&
-            (unsigned)wi < (unsigned)a.Wi)
-          v = a.x[((((long)n * a.Cin + ci) * a.Di + di) * a.Hi + hi) * a.Wi + wi];
-        in_lds[row * IWP + 3 + j] = v;
-      }
+    if constexpr (VEC) {
+      store_regs();
     } else {
       for (int it = tid; it < ROWS * IW; it += 256) {
         const int row = it / IW, j = it % IW;
@@ -113,9 +156,6 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
           v = a.x[((((long)n * a.Cin + ci) * a.Di + di) * a.Hi + hi) * a.Wi + wi];
         in_lds[row * IWP + 3 + j] = v;
       }
-    }
-    {
-      constexpr int WQ = CK * CO / 4;
       for (int it = tid; it < 27 * WQ; it += 256) {
         const int tap = it / WQ, q = it % WQ;
         *(float4*)(w_lds + tap * CK * CO + 4 * q) =
@@ -123,6 +163,9 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
       }
     }
     __syncthreads();
+    if constexpr (VEC) {
+      if (ci0 + CK < a.CinPad) load_regs(ci0 + CK);
+    }
 #pragma unroll 1
     for (int kd = 0; kd < 3; ++kd) {
 #pragma unroll 1
@@ -149,10 +192,10 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
     }
   }
 
-  const int w = w0 + l31;
+  const int w = w0 + wl;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int r0 = wv * NT + t, d = d0 + r0 / TH, h = h0 + r0 % TH;
+    const int r0 = (wv * NT + t) * RPT + hsel, d = d0 + r0 / TH, h = h0 + r0 % TH;
     if (d >= a.Do || h >= a.Ho || w >= a.Wo) continue;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
@@ -166,6 +209,9 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
       }
   }
 }
+
+template <int S, int CT, int CK, int TD, int TH, int TW>
+static int launch_conv3(ConvArgs& a, bool vec, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // Transposed 3x3x3, stride 2, pad 1, output_padding 1 (out = 2*in).  out[o] += x[m] W[k] with
@@ -378,6 +424,17 @@ static int launch_conv(KernelT kernel, const ConvArgs& a, int grid, size_t lds, 
   return dca_launch_status();
 }
 
+template <int S, int CT, int CK, int TD, int TH, int TW>
+static int launch_conv3(ConvArgs& a, bool vec, hipStream_t stream) {
+  constexpr int ID = (TD - 1) * S + 3, IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
+  constexpr int IWP = ((3 + IW + 3) / 4) * 4;
+  const size_t lds = (size_t)(CK * ID * IH * IWP + 27 * CK * CT * 32) * 4;
+  a.nTD = cdiv(a.Do, TD); a.nTH = cdiv(a.Ho, TH); a.nTW = cdiv(a.Wo, TW);
+  const int grid = a.N * a.nTD * a.nTH * a.nTW;
+  return vec ? launch_conv(conv3_mfma_kernel<S, CT, CK, TD, TH, TW, true>, a, grid, lds, stream)
+             : launch_conv(conv3_mfma_kernel<S, CT, CK, TD, TH, TW, false>, a, grid, lds, stream);
+}
+
 extern "C" int dca_conv3d_prep_weight(const float* w, float* wt, int A, int B, int Apad, int Bpad, int K,
                                       int src_ab, int flip, hipStream_t stream) {
   DCA_REQUIRE(w && wt && A > 0 && B > 0 && Apad >= A && Bpad >= B && (K == 1 || K == 27));
@@ -433,21 +490,25 @@ extern "C" int dca_conv3d_forward(const float* x, const float* x2, const float* 
   DCA_REQUIRE(Cout <= 64 && CinPad % 8 == 0);
   if (stride == 1) {
     DCA_REQUIRE(Do == Di && Ho == Hi && Wo == Wi);
-    a.nTD = cdiv(Do, 2); a.nTH = cdiv(Ho, 8); a.nTW = cdiv(Wo, 32);
-    const int grid = N * a.nTD * a.nTH * a.nTW;
-    if (Cout <= 32) {
-      const size_t lds = (size_t)(8 * 4 * 10 * 40 + 27 * 8 * 32) * 4;
-      return vec ? launch_conv(conv3_mfma_kernel<1, 1, 8, 2, 8, true>, a, grid, lds, stream)
-                 : launch_conv(conv3_mfma_kernel<1, 1, 8, 2, 8, false>, a, grid, lds, stream);
+    // candidate tile shapes (TD, TH, TW); pick the one with the fewest padded voxels, then the fewest blocks
+    struct Shape { int td, th, tw; };
+    const Shape shapes[3] = {{2, 8, 32}, {4, 4, 32}, {4, 8, 16}};
+    int best = 0;
+    long best_cost = -1;
+    for (int i = 0; i < 3; ++i) {
+      const long cost = (long)cdiv(Do, shapes[i].td) * shapes[i].td * cdiv(Ho, shapes[i].th) * shapes[i].th *
+                        cdiv(Wo, shapes[i].tw) * shapes[i].tw;
+      if (best_cost < 0 || cost < best_cost) { best = i; best_cost = cost; }
     }
-    const size_t lds = (size_t)(4 * 4 * 10 * 40 + 27 * 4 * 64) * 4;
-    return vec ? launch_conv(conv3_mfma_kernel<1, 2, 4, 2, 8, true>, a, grid, lds, stream)
-               : launch_conv(conv3_mfma_kernel<1, 2, 4, 2, 8, false>, a, grid, lds, stream);
+    if (Cout <= 32) {
+      if (best == 0) return launch_conv3<1, 1, 8, 2, 8, 32>(a, vec, stream);
+      if (best == 1) return launch_conv3<1, 1, 8, 4, 4, 32>(a, vec, stream);
+      return launch_conv3<1, 1, 8, 4, 8, 16>(a, vec, stream);
+    }
+    if (best == 0) return launch_conv3<1, 2, 4, 2, 8, 32>(a, vec, stream);
+    if (best == 1) return launch_conv3<1, 2, 4, 4, 4, 32>(a, vec, stream);
+    return launch_conv3<1, 2, 4, 4, 8, 16>(a, vec, stream);
   }
   DCA_REQUIRE(stride == 2 && Do == (Di + 1) / 2 && Ho == (Hi + 1) / 2 && Wo == (Wi + 1) / 2);
-  a.nTD = cdiv(Do, 2); a.nTH = cdiv(Ho, 4); a.nTW = cdiv(Wo, 32);
-  const int grid = N * a.nTD * a.nTH * a.nTW;
-  const size_t lds = (size_t)(4 * 5 * 9 * 68 + 27 * 4 * 64) * 4;
-  return vec ? launch_conv(conv3_mfma_kernel<2, 2, 4, 2, 4, true>, a, grid, lds, stream)
-             : launch_conv(conv3_mfma_kernel<2, 2, 4, 2, 4, false>, a, grid, lds, stream);
+  return launch_conv3<2, 2, 4, 2, 4, 32>(a, vec, stream);
 }
