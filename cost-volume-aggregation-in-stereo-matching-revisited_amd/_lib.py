@@ -16,6 +16,8 @@ SIGNATURES = {
     "dca_concat_volume_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "dca_softargmin_fwd": (_i, [_p, _p, _i, _i, _l, _i, _p]),
     "dca_softargmin_bwd": (_i, [_p, _p, _p, _i, _i, _l, _i, _p]),
+    "dca_up_softargmin_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "dca_up_softargmin_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "dca_conv3d_prep_weight": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dca_conv3d_forward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _f] + [_i] * 14 + [_p]),
     "dca_conv3d_wgrad_workspace": (_l, [_i] * 8),

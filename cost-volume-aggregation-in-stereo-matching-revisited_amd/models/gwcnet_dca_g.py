@@ -135,7 +135,7 @@ class GwcNet(nn.Module):
             res["pred0"] = ops.softmax_dim1(self.classif0(cost0).squeeze(1))
             res["pred_dca1"] = ops.softmax_dim1(ops.trilinear_upsample(prob_volume1, 2).squeeze(1))
             res["pred_dca2"] = ops.softmax_dim1(ops.trilinear_upsample(prob_volume2, 2).squeeze(1))
-            res["pred_dca3"] = ops.softargmin(ops.trilinear_upsample(prob_volume3, 8).squeeze(1))
+            res["pred_dca3"] = ops.up_softargmin(prob_volume3.squeeze(1), 8)
             res["pred1"] = ops.softmax_dim1(self.classif1(out1).squeeze(1))
             res["pred2"] = ops.softmax_dim1(self.classif2(out2).squeeze(1))
         return res

@@ -155,6 +155,43 @@ def regression(x):
     return _SoftArgmin.apply(x, 2)
 
 
+class _UpSoftArgmin(torch.autograd.Function):
+    """trilinear x s up-sampling + softmax(dim 1) + disparity regression, fused (gwcnet_dca_g.py:261-264)."""
+
+    @staticmethod
+    def forward(ctx, logits, scale):
+        logits = _req(logits, "up_softargmin")
+        B, n, hc, wc = logits.shape
+        disp = torch.empty((B, 1, scale * hc, scale * wc), device=logits.device, dtype=torch.float32)
+        with torch.cuda.device_of(logits):
+            _chk(_L().dca_up_softargmin_fwd(_ptr(logits), _ptr(disp), B, n, hc, wc, scale, _stream()),
+                 "dca_up_softargmin_fwd")
+        ctx.save_for_backward(logits)
+        ctx.scale = scale
+        return disp
+
+    @staticmethod
+    def backward(ctx, g):
+        (logits,) = ctx.saved_tensors
+        g = _req(g, "up_softargmin.backward")
+        B, n, hc, wc = logits.shape
+        s = ctx.scale
+        g1 = torch.empty((B, n, s * hc, s * wc), device=logits.device, dtype=torch.float32)
+        gl = torch.empty_like(logits)
+        with torch.cuda.device_of(logits):
+            _chk(_L().dca_up_softargmin_bwd(_ptr(logits), _ptr(g), _ptr(g1), _ptr(gl), B, n, hc, wc, s, _stream()),
+                 "dca_up_softargmin_bwd")
+        return gl, None
+
+
+def up_softargmin(logits, scale):
+    """(B,n,hc,wc) logits -> (B,1,s*hc,s*wc) expected disparity over s*n bins; falls back to the unfused kernels
+    for n > 32 or scales other than 2 / 8."""
+    if logits.shape[1] > 32 or logits.shape[1] < 2 or scale not in (2, 8):
+        return softargmin(trilinear_upsample(logits.unsqueeze(1), scale).squeeze(1))
+    return _UpSoftArgmin.apply(logits, int(scale))
+
+
 # ------------------------------------------------------------------------------------------------
 # 3D convolutions
 # ------------------------------------------------------------------------------------------------

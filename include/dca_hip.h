@@ -44,6 +44,13 @@ int dca_softargmin_fwd(const float* x, float* out, int B, int K, long HW, int mo
 int dca_softargmin_bwd(const float* aux, const float* g, float* gx, int B, int K, long HW, int mode,
                        hipStream_t stream);
 
+/* Fused training head: disparity_regression(F.softmax(F.upsample(logits[:,None], scale_factor=(s,s,s),
+ * mode='trilinear').squeeze(1), 1), s*n)  -- models/gwcnet_dca_g.py:261-264 (s = 8).  logits: (B,n,hc,wc), n <= 32;
+ * disp: (B,1,s*hc,s*wc).  bwd needs g1 = B*n*(s*hc)*(s*wc) floats of scratch. */
+int dca_up_softargmin_fwd(const float* logits, float* disp, int B, int n, int hc, int wc, int scale, hipStream_t stream);
+int dca_up_softargmin_bwd(const float* logits, const float* gdisp, float* g1, float* glogits, int B, int n, int hc,
+                          int wc, int scale, hipStream_t stream);
+
 /* ---- 3D convolutions (nn.Conv3d / nn.ConvTranspose3d, bias=False) ----------------------------------
  * models/submodule.py:121-124 (convbn_3d), models/gwcnet_dca_g.py:141-168, models/augment/cva.py:13-55,
  * models/augment/SelfAttention_bn.py:136-160.

@@ -269,6 +269,22 @@ def test_trilinear(scale, dims):
     close(y, yr, 2e-6); close(gx, gxr, 1e-5)
 
 
+@pytest.mark.parametrize("scale,shape", [(8, (2, 4, 3, 5)), (8, (1, 24, 4, 6)), (2, (2, 6, 5, 7)), (8, (1, 2, 2, 2))])
+def test_up_softargmin(scale, shape):
+    """fused x8 head (gwcnet_dca_g.py:261-264) against upsample -> softmax -> regression on the CPU"""
+    _, ops = _mods()
+    x = seeded_tensor("us.x", shape) * 2
+    xc = cpu_leaf(x)
+    up = F.interpolate(xc.unsqueeze(1), scale_factor=(scale,) * 3, mode="trilinear").squeeze(1)
+    yr = O.disparity_regression(F.softmax(up, 1), scale * shape[1])
+    gy = seeded_tensor("us.g", yr.shape)
+    (gxr,) = torch.autograd.grad((yr * gy).sum(), [xc])
+    xg = gpu(x, True)
+    y = ops.up_softargmin(xg, scale)
+    (gx,) = torch.autograd.grad((y * gy.to(DEV)).sum(), [xg])
+    close(y, yr, 2e-6, "fwd"); close(gx, gxr, 2e-5, "bwd")
+
+
 # ------------------------------------------------------------------------------------- DCA units
 @pytest.mark.parametrize("shape", [(2, 32, 4, 8, 16), (1, 32, 6, 5, 9), (2, 32, 24, 9, 30)])
 def test_context_inject(shape):
