@@ -22,10 +22,9 @@ SIGNATURES = {
     "dca_conv3d_forward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _f] + [_i] * 14 + [_p]),
     "dca_conv3d_wgrad_workspace": (_l, [_i] * 8),
     "dca_conv3d_wgrad": (_i, [_p, _p, _p, _p] + [_i] * 11 + [_l, _l, _p]),
-    "dca_conv3d_c1_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "dca_conv3d_c1_gather": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "dca_conv3d_c1_expand": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "dca_conv3d_c1_bwd_data": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
-    "dca_conv3d_c1_wgrad_workspace": (_l, [_i] * 5),
-    "dca_conv3d_c1_wgrad": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "dca_bn_num_chunks": (_i, [_i, _l]),
     "dca_bn_stats": (_i, [_p, _p, _i, _i, _l, _p]),
     "dca_bn_finalize": (_i, [_p, _i, _d, _p, _p, _p, _p, _f, _f, _i, _p, _i, _p]),

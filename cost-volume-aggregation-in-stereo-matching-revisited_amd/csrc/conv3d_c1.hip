@@ -2,10 +2,9 @@
 //
 // Replaces nn.Conv3d(32, 1, kernel_size=3, padding=1, bias=False): `classif{0..3}.2`
 // (models/gwcnet_dca_g.py:154-168) and `cva.classify.2` (models/augment/cva.py:51-53), forward, backward-data and
-// weight gradient.  With a single output channel there is no Cin x Cout contraction for the matrix cores (an MFMA
-// tile would waste 31 of its 32 rows), so this is a bandwidth/VALU kernel: input halo tiles in LDS, every thread
-// owns 4 consecutive W positions (one 16-byte LDS read + 2 scalars per (c, kd, kh) row feed 12 FMAs), 16-byte
-// coalesced global loads and stores.
+// weight gradient.  With a single output channel a direct MFMA tile would waste 31 of its 32 rows; instead the 27
+// taps become the GEMM's output axis (see "tap expansion" below) for forward and weight gradient, and the
+// backward-data pass is a VALU kernel (dy halo tile in LDS, 4 consecutive W positions per thread).
 #include "dca_common.h"
 #include "../../include/dca_hip.h"
 
@@ -67,49 +66,6 @@ __device__ __forceinline__ void tile_coords(const C1Args& a, int tile, int& n, i
   d0 = td * TD; h0 = th * TH; w0 = tw * TW;
 }
 
-// ------------------------------------------------------------------------------------------ forward
-__global__ __launch_bounds__(256) void c1_fwd_kernel(C1Args a) {
-  __shared__ __attribute__((aligned(16))) float in_lds[CK * ID * IH * IWP];
-  __shared__ __attribute__((aligned(16))) float w_lds[CK * 9 * 4];
-  const int tid = threadIdx.x, wq = tid & 7, row = tid >> 3, dl = row >> 3, hl = row & 7;
-  int n, d0, h0, w0;
-  tile_coords(a, xcd_remap(blockIdx.x, gridDim.x), n, d0, h0, w0);
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int c0 = 0; c0 < a.C; c0 += CK) {
-    __syncthreads();
-    stage_tile(a.x, in_lds, n, a.C, c0, CK, a.D, a.H, a.W, d0, h0, w0, a.vec, tid);
-    if (tid < CK * 27) {
-      const int c = tid / 27, t = tid % 27;
-      w_lds[(c * 9 + t / 3) * 4 + t % 3] = (c0 + c < a.C) ? a.w[(c0 + c) * 27 + t] : 0.f;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < CK; ++c)
-#pragma unroll
-      for (int r9 = 0; r9 < 9; ++r9) {
-        const float* p = in_lds + ((c * ID + dl + r9 / 3) * IH + hl + r9 % 3) * IWP + 4 * wq;
-        const float xm = p[3], xp = p[8];
-        const float4 xv = *(const float4*)(p + 4);
-        const float4 wv = *(const float4*)(w_lds + (c * 9 + r9) * 4);
-        acc[0] += wv.x * xm + wv.y * xv.x + wv.z * xv.y;
-        acc[1] += wv.x * xv.x + wv.y * xv.y + wv.z * xv.z;
-        acc[2] += wv.x * xv.y + wv.y * xv.z + wv.z * xv.w;
-        acc[3] += wv.x * xv.z + wv.y * xv.w + wv.z * xp;
-      }
-  }
-  const int d = d0 + dl, h = h0 + hl, w = w0 + 4 * wq;
-  if (d < a.D && h < a.H && w < a.W) {
-    float* o = a.out + (((long)n * a.D + d) * a.H + h) * a.W + w;
-    if (a.vec) {
-      *(float4*)o = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (w + j < a.W) o[j] = acc[j];
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------ backward-data
 // dx[n,ci,v] = sum_k dy[n,0,v+1-k] w[ci][k] = sum_t dy[v+t-1] w[ci][26-t]
 __global__ __launch_bounds__(256) void c1_bwd_data_kernel(C1Args a) {
@@ -154,70 +110,56 @@ __global__ __launch_bounds__(256) void c1_bwd_data_kernel(C1Args a) {
   }
 }
 
-// ------------------------------------------------------------------------------------------ weight gradient
-// dW[ci][t] = sum_{n,v} dy[v] x[ci][v+t-1]; persistent workgroups, 4 channels at a time in registers (4 x 27
-// accumulators per thread), one block-level reduction per (worker, channel chunk); partials summed by a second pass.
-__global__ __launch_bounds__(256) void c1_wgrad_kernel(C1Args a) {
-  __shared__ __attribute__((aligned(16))) float in_lds[CK * ID * IH * IWP];
-  __shared__ float red[4][CK * 27];
-  const int tid = threadIdx.x, wq = tid & 7, row = tid >> 3, dl = row >> 3, hl = row & 7;
-  for (int c0 = 0; c0 < a.C; c0 += CK) {
-    float acc[CK][27];
+// ------------------------------------------------------------------------------------------ tap expansion
+// The forward and the weight gradient are expressed as 1x1x1 GEMMs over a 27-channel "tap" axis so they run on
+// the matrix-core kernels of conv3d_mfma.hip / conv3d_wgrad.hip:
+//   forward : T[t][v'] = sum_ci w[ci][t] x[ci][v']  (conv1_mfma_kernel, 32 -> 27)      y[v] = sum_t T[t][v + t - 1]
+//   wgrad   : G[t][v'] = dy[v' - (t - 1)]                                              dW[ci][t] = sum_v' x[ci][v'] G[t][v']
+// (t - 1) is the 3D tap offset (kd-1, kh-1, kw-1); out-of-volume positions contribute zero.
+__global__ void c1_gather_kernel(const float* __restrict__ T, float* __restrict__ y, int N, int D, int H, int W) {
+  const long DHW = (long)D * H * W, total = (long)N * DHW;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int w = idx % W;
+    long t = idx / W;
+    const int h = t % H; t /= H;
+    const int d = t % D;
+    const long n = t / D;
+    const float* p = T + n * 27 * DHW;
+    float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < CK; ++c)
+    for (int kd = 0; kd < 3; ++kd) {
+      const int dd = d + kd - 1;
+      if ((unsigned)dd >= (unsigned)D) continue;
 #pragma unroll
-      for (int t = 0; t < 27; ++t) acc[c][t] = 0.f;
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-      int n, d0, h0, w0;
-      tile_coords(a, tile, n, d0, h0, w0);
-      __syncthreads();
-      stage_tile(a.x, in_lds, n, a.C, c0, CK, a.D, a.H, a.W, d0, h0, w0, a.vec, tid);
-      const int d = d0 + dl, h = h0 + hl, w = w0 + 4 * wq;
-      float gv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (d < a.D && h < a.H) {
-        const float* gp = a.dy + (((long)n * a.D + d) * a.H + h) * a.W + w;
-        if (a.vec) {
-          if (w < a.W) { const float4 t4 = *(const float4*)gp; gv[0] = t4.x; gv[1] = t4.y; gv[2] = t4.z; gv[3] = t4.w; }
-        } else {
+      for (int kh = 0; kh < 3; ++kh) {
+        const int hh = h + kh - 1;
+        if ((unsigned)hh >= (unsigned)H) continue;
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (w + j < a.W) gv[j] = gp[j];
+        for (int kw = 0; kw < 3; ++kw) {
+          const int ww = w + kw - 1;
+          if ((unsigned)ww < (unsigned)W) s += p[((kd * 3 + kh) * 3 + kw) * DHW + ((long)dd * H + hh) * W + ww];
         }
       }
-      __syncthreads();
-#pragma unroll
-      for (int c = 0; c < CK; ++c)
-#pragma unroll
-        for (int r9 = 0; r9 < 9; ++r9) {
-          const float* p = in_lds + ((c * ID + dl + r9 / 3) * IH + hl + r9 % 3) * IWP + 4 * wq;
-          const float4 v = *(const float4*)(p + 4);
-          const float xs[6] = {p[3], v.x, v.y, v.z, v.w, p[8]};
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw)
-            acc[c][r9 * 3 + kw] += gv[0] * xs[kw] + gv[1] * xs[kw + 1] + gv[2] * xs[kw + 2] + gv[3] * xs[kw + 3];
-        }
     }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < CK; ++c)
-#pragma unroll
-      for (int t = 0; t < 27; ++t) {
-        const float s = wave_sum(acc[c][t]);
-        if ((tid & 63) == 0) red[tid >> 6][c * 27 + t] = s;
-      }
-    __syncthreads();
-    if (tid < CK * 27 && c0 + tid / 27 < a.C)
-      a.out[((long)blockIdx.x * a.C + c0 + tid / 27) * 27 + tid % 27] =
-          (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    y[idx] = s;
   }
 }
 
-__global__ void c1_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nblk, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += part[(long)b * n + i];
-  dw[i] = s;
+__global__ void c1_expand_kernel(const float* __restrict__ dy, float* __restrict__ G, int N, int D, int H, int W) {
+  const long DHW = (long)D * H * W, total = (long)N * 27 * DHW;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int w = idx % W;
+    long t = idx / W;
+    const int h = t % H; t /= H;
+    const int d = t % D; t /= D;
+    const int tap = t % 27;
+    const long n = t / 27;
+    const int dd = d - (tap / 9 - 1), hh = h - ((tap / 3) % 3 - 1), ww = w - (tap % 3 - 1);
+    float v = 0.f;
+    if ((unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W)
+      v = dy[n * DHW + ((long)dd * H + hh) * W + ww];
+    G[idx] = v;
+  }
 }
 
 int fill_args(C1Args& a, int N, int C, int D, int H, int W, const void* p0, const void* p1, const void* p2) {
@@ -231,16 +173,6 @@ int fill_args(C1Args& a, int N, int C, int D, int H, int W, const void* p0, cons
 }
 }  // namespace
 
-extern "C" int dca_conv3d_c1_fwd(const float* x, const float* w, float* y, int N, int C, int D, int H, int W,
-                                 hipStream_t stream) {
-  DCA_REQUIRE(x && w && y && N > 0 && C > 0 && D > 0 && H > 0 && W > 0);
-  C1Args a;
-  a.x = x; a.w = w; a.dy = nullptr; a.out = y;
-  DCA_REQUIRE(fill_args(a, N, C, D, H, W, x, y, nullptr) == 0);
-  hipLaunchKernelGGL(c1_fwd_kernel, dim3(a.ntiles), dim3(256), 0, stream, a);
-  return dca_launch_status();
-}
-
 extern "C" int dca_conv3d_c1_bwd_data(const float* dy, const float* w, float* dx, int N, int C, int D, int H, int W,
                                       hipStream_t stream) {
   DCA_REQUIRE(dy && w && dx && N > 0 && C > 0 && C <= 256 && D > 0 && H > 0 && W > 0);
@@ -251,20 +183,18 @@ extern "C" int dca_conv3d_c1_bwd_data(const float* dy, const float* w, float* dx
   return dca_launch_status();
 }
 
-extern "C" long dca_conv3d_c1_wgrad_workspace(int N, int C, int D, int H, int W) {
-  const long nt = (long)N * cdiv(D, TD) * cdiv(H, TH) * cdiv(W, TW);
-  const long nblk = nt < 512 ? nt : 512;
-  return nblk * C * 27;
+extern "C" int dca_conv3d_c1_gather(const float* T, float* y, int N, int D, int H, int W, hipStream_t stream) {
+  DCA_REQUIRE(T && y && N > 0 && D > 0 && H > 0 && W > 0);
+  const long total = (long)N * D * H * W;
+  const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(c1_gather_kernel, dim3(grid), dim3(256), 0, stream, T, y, N, D, H, W);
+  return dca_launch_status();
 }
 
-extern "C" int dca_conv3d_c1_wgrad(const float* x, const float* dy, float* part, float* dw, int N, int C, int D, int H,
-                                   int W, hipStream_t stream) {
-  DCA_REQUIRE(x && dy && part && dw && N > 0 && C > 0 && D > 0 && H > 0 && W > 0);
-  C1Args a;
-  a.x = x; a.w = nullptr; a.dy = dy; a.out = part;
-  DCA_REQUIRE(fill_args(a, N, C, D, H, W, x, dy, nullptr) == 0);
-  const int nblk = a.ntiles < 512 ? a.ntiles : 512;
-  hipLaunchKernelGGL(c1_wgrad_kernel, dim3(nblk), dim3(256), 0, stream, a);
-  hipLaunchKernelGGL(c1_wgrad_reduce_kernel, dim3(cdiv(C * 27, 256)), dim3(256), 0, stream, part, dw, nblk, C * 27);
+extern "C" int dca_conv3d_c1_expand(const float* dy, float* G, int N, int D, int H, int W, hipStream_t stream) {
+  DCA_REQUIRE(dy && G && N > 0 && D > 0 && H > 0 && W > 0);
+  const long total = (long)N * 27 * D * H * W;
+  const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(c1_expand_kernel, dim3(grid), dim3(256), 0, stream, dy, G, N, D, H, W);
   return dca_launch_status();
 }

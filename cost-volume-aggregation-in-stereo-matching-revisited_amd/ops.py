@@ -262,15 +262,18 @@ def _wgrad(x, dy, dw_view_ptr_tensor, dst_offset, Cx, Cy, ksize, stride, s_cy, s
 
 
 class _Conv3dC1(torch.autograd.Function):
-    """nn.Conv3d(C, 1, 3, padding=1, bias=False): the logit heads (VALU/bandwidth kernels, no MFMA waste)."""
+    """nn.Conv3d(C, 1, 3, padding=1, bias=False): the logit heads.  The 27 taps become a GEMM axis so forward and
+    weight gradient run on the 1x1x1 matrix-core kernels (see include/dca_hip.h); C must be 32 or 64."""
 
     @staticmethod
     def forward(ctx, x, weight):
         x, weight = _req(x, "conv3d"), _req(weight, "conv3d.weight")
         N, C, D, H, W = x.shape
-        y = torch.empty((N, 1, D, H, W), device=x.device, dtype=torch.float32)
         with torch.cuda.device_of(x):
-            _chk(_L().dca_conv3d_c1_fwd(_ptr(x), _ptr(weight), _ptr(y), N, C, D, H, W, _stream()), "dca_conv3d_c1_fwd")
+            wt, cpad = _prep_weight(weight, C, 27, 1, 1, 0, 1, 1, False)        # wt[ci][tap] = w[0, ci, tap]
+            T = _conv_launch(x, None, wt, cpad, C, C, 27, 1, 1, False)          # (N,27,D,H,W)
+            y = torch.empty((N, 1, D, H, W), device=x.device, dtype=torch.float32)
+            _chk(_L().dca_conv3d_c1_gather(_ptr(T), _ptr(y), N, D, H, W, _stream()), "dca_conv3d_c1_gather")
         ctx.save_for_backward(x, weight)
         return y
 
@@ -287,11 +290,10 @@ class _Conv3dC1(torch.autograd.Function):
                 _chk(lib.dca_conv3d_c1_bwd_data(_ptr(dy), _ptr(weight), _ptr(gx), N, C, D, H, W, _stream()),
                      "dca_conv3d_c1_bwd_data")
             if ctx.needs_input_grad[1]:
+                G = torch.empty((N, 27, D, H, W), device=x.device, dtype=torch.float32)
+                _chk(lib.dca_conv3d_c1_expand(_ptr(dy), _ptr(G), N, D, H, W, _stream()), "dca_conv3d_c1_expand")
                 gw = torch.empty_like(weight)
-                part = torch.empty((lib.dca_conv3d_c1_wgrad_workspace(N, C, D, H, W),), device=x.device,
-                                   dtype=torch.float32)
-                _chk(lib.dca_conv3d_c1_wgrad(_ptr(x), _ptr(dy), _ptr(part), _ptr(gw), N, C, D, H, W, _stream()),
-                     "dca_conv3d_c1_wgrad")
+                _wgrad(x, G, gw, 0, C, 27, 1, 1, 1, 27)                          # dw[ci*27 + tap]
         return gx, gw
 
 
@@ -365,7 +367,8 @@ class _Conv3d(torch.autograd.Function):
 
 
 def conv3d(x, weight, stride=1, transposed=False, x2=None):
-    if (not transposed and x2 is None and weight.shape[0] == 1 and weight.shape[2] == 3 and int(stride) == 1):
+    if (not transposed and x2 is None and weight.shape[0] == 1 and weight.shape[2] == 3 and int(stride) == 1
+            and weight.shape[1] in (32, 64)):
         return _Conv3dC1.apply(x, weight)
     return _Conv3d.apply(x, x2, weight, int(stride), bool(transposed))
 

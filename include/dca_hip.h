@@ -88,14 +88,14 @@ int dca_conv3d_wgrad(const float* x, const float* dy, float* part, float* dw, in
 
 /* Single-output-channel 3x3x3 convolution (the logit heads: nn.Conv3d(32, 1, 3, padding=1, bias=False),
  * models/gwcnet_dca_g.py:154-168 `classif*.2`, models/augment/cva.py:51-53 `classify.2`).  w is the PyTorch weight
- * (1,C,3,3,3) as is.  fwd: x (N,C,D,H,W) -> y (N,1,D,H,W); bwd_data: dy (N,1,..) -> dx (N,C,..);
- * wgrad: dw (1,C,27) with `part` = dca_conv3d_c1_wgrad_workspace(...) floats of scratch. */
-int dca_conv3d_c1_fwd(const float* x, const float* w, float* y, int N, int C, int D, int H, int W, hipStream_t stream);
+ * (1,C,3,3,3) as is.  The 27 taps become a GEMM axis so forward / weight gradient reuse the matrix-core kernels:
+ *   forward: T (N,27,D,H,W) = dca_conv3d_forward(ksize 1, weight laid out [ci][tap]);  y = dca_conv3d_c1_gather(T)
+ *   wgrad:   G (N,27,D,H,W) = dca_conv3d_c1_expand(dy);  dW = dca_conv3d_wgrad(x, G, ksize 1, s_cy 1, s_cx 27)
+ *   bwd_data: dy (N,1,..) -> dx (N,C,..) directly. */
+int dca_conv3d_c1_gather(const float* T, float* y, int N, int D, int H, int W, hipStream_t stream);
+int dca_conv3d_c1_expand(const float* dy, float* G, int N, int D, int H, int W, hipStream_t stream);
 int dca_conv3d_c1_bwd_data(const float* dy, const float* w, float* dx, int N, int C, int D, int H, int W,
                            hipStream_t stream);
-long dca_conv3d_c1_wgrad_workspace(int N, int C, int D, int H, int W);
-int dca_conv3d_c1_wgrad(const float* x, const float* dy, float* part, float* dw, int N, int C, int D, int H, int W,
-                        hipStream_t stream);
 
 /* ---- BatchNorm3d + activation + residual -------------------------------------------------------------
  * nn.BatchNorm3d defaults (eps 1e-5, momentum 0.1) as used by convbn_3d, models/submodule.py:121-124.
