@@ -224,6 +224,14 @@ def main():
         }
         roof = kernel_roofline(device)
         names = list(roof)
+        # HBM bytes per launch from the PMC passes committed under profiles/ (cannot be collected inside this run)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            for n, key in zip(names, [k for k in pmc if not k.startswith("_")]):
+                roof[n]["traffic"] = round(pmc[key]["hbm_bytes_per_launch"])
+                roof[n]["algorithmic_bytes"] = pmc[key]["algorithmic_bytes"]
+        except (OSError, KeyError, ValueError):
+            pass
         line["roofline"] = dict(roof[names[0]], kernel=names[0])
         line["roofline_other"] = {n: roof[n] for n in names[1:]}
         if world == 1 and not args.no_cpu_baseline:

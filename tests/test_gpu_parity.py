@@ -440,3 +440,43 @@ def test_cpu_tensors_raise():
     _, ops = _mods()
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.gwc_volume(torch.zeros(1, 8, 2, 4), torch.zeros(1, 8, 2, 4), 2, 1)
+
+
+# ------------------------------------------------------------------------------------- full size (BASELINE shape)
+@pytest.mark.timeout(900)
+def test_full_size_eval_matches_oracle():
+    """544x960, D=192 (BASELINE.json's shape): final 1/4-res disparity of the fused-inference HIP path vs the CPU
+    oracle on identical seeded inputs/weights.  north_star gate: 1e-3 abs on the full-res disparity = 2.5e-4 on
+    pred4_q (the x4 of `prop`)."""
+    from dcanet_amd.models.gwcnet_dca_g import GwcNet
+    m = load_seeded(GwcNet(192, use_concat_volume=False)).to(DEV).eval()
+    fL, fR = seeded_tensor("full.fL", (1, 320, 136, 240)), seeded_tensor("full.fR", (1, 320, 136, 240))
+    with torch.no_grad():
+        r = m.hot_path(fL.to(DEV), fR.to(DEV))
+        got = r["pred4_q"].cpu()
+        sd = O.seeded_state_dict(O.hot_path_shapes(False))
+        ref = O.hot_path(sd, fL, fR, 192, False)
+    err = (got - ref["pred4_q"]).abs()
+    assert ref["pred4_q"].std() > 1.0, "degenerate test: disparity map is flat"
+    assert err.max().item() <= 2.5e-4, f"max |pred4_q - oracle| = {err.max().item():.3e} (mean {err.mean().item():.3e})"
+    close(r["prob_volume2"].squeeze(1), ref["prob_volume2"].squeeze(1), 5e-5, "prob_volume2")
+
+
+def test_full_size_properties():
+    """size-independent properties at 544x960/D=192: the gwc volume is zero for x < i, its disparity-0 plane equals
+    groupwise_correlation, soft-argmin stays inside [0, d-1], and fused inference == unfused kernels."""
+    from dcanet_amd.models.gwcnet_dca_g import GwcNet
+    from dcanet_amd.models.submodule import build_gwc_volume, groupwise_correlation
+    _, ops = _mods()
+    fL, fR = seeded_tensor("full.fL", (1, 320, 136, 240)).to(DEV), seeded_tensor("full.fR", (1, 320, 136, 240)).to(DEV)
+    vol = build_gwc_volume(fL, fR, 48, 40)
+    assert vol.shape == (1, 40, 48, 136, 240)
+    tri = torch.arange(240, device=DEV)[None, :] < torch.arange(48, device=DEV)[:, None]      # (i, x): x < i
+    assert (vol[0, :, tri.unsqueeze(1).expand(48, 136, 240)] == 0).all()
+    assert torch.equal(vol[:, :, 0], groupwise_correlation(fL, fR, 40))
+    m = load_seeded(GwcNet(192, use_concat_volume=False)).to(DEV).eval()
+    with torch.no_grad():
+        fused = m.hot_path(fL, fR)["pred4_q"]
+    unfused = m.hot_path(fL.requires_grad_(), fR)["pred4_q"]
+    assert fused.min() >= 0 and fused.max() <= 47
+    assert (fused - unfused).abs().max().item() <= 1e-4
