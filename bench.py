@@ -98,8 +98,8 @@ def kernel_roofline(device):
     out = {}
     with torch.no_grad():
         wt, cpad = ops._prep_weight(wgt, 32, 32, 27, 0, 0, 3, 1, False)
-        for name, fn in (("conv3_mfma_kernel<S1,Cout32,CK8,2x8x32> (3x3x3 32->32 @1/4 res)",
-                          lambda: ops._conv_launch(x, None, wt, cpad, 32, 32, 32, 3, 1, False)),
+        for name, fn in (("conv3_mfma_kernel<S1,Cout32,CK8,tile 4x8x16> (3x3x3 32->32 @1/4 res)",
+                          lambda: ops.conv3d_prepared(x, wt, 32, cpad, 32, 3, 1, False)),
                          ("wgrad3_kernel<S1> (+reduce) (dW of 3x3x3 32->32 @1/4 res)",
                           lambda: ops._wgrad(x, x, wgt.new_empty(wgt.shape), 0, 32, 32, 3, 1, 32 * 27, 27))):
             for _ in range(2):

@@ -25,13 +25,14 @@ struct ConvArgs {
   const float* res_post;
   float slope;
   int N, Cin, Cout, CinPad;
+  int CoutTotal, co_off;  // this launch writes channels [co_off, co_off+Cout) of a CoutTotal-channel output
   int Di, Hi, Wi, Do, Ho, Wo;
   int nTD, nTH, nTW;
   long xs_n, x2s_n;  // batch strides (floats) of x / x2 (1x1 kernel only)
 };
 
 __device__ __forceinline__ float epilogue(const ConvArgs& a, float v, int co, long idx) {
-  if (a.scale) v = v * a.scale[co] + a.shift[co];
+  if (a.scale) v = v * a.scale[a.co_off + co] + a.shift[a.co_off + co];
   if (a.res_pre) v += a.res_pre[idx];
   v = act_apply(v, a.slope);
   if (a.res_post) v += a.res_post[idx];
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
       for (int r = 0; r < 16; ++r) {
         const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (co < a.Cout) {
-          const long idx = ((((long)n * a.Cout + co) * a.Do + d) * a.Ho + h) * a.Wo + w;
+          const long idx = ((((long)n * a.CoutTotal + a.co_off + co) * a.Do + d) * a.Ho + h) * a.Wo + w;
           a.y[idx] = epilogue(a, acc[t][ct][r], co, idx);
         }
       }
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void deconv3_mfma_kernel(ConvArgs a) {
         for (int r = 0; r < 16; ++r) {
           const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
           if (co < a.Cout) {
-            const long idx = ((((long)n * a.Cout + co) * a.Do + d) * a.Ho + h) * a.Wo + 2 * mw;
+            const long idx = ((((long)n * a.CoutTotal + a.co_off + co) * a.Do + d) * a.Ho + h) * a.Wo + 2 * mw;
             float2 o;
             o.x = epilogue(a, acc[(pd * 2 + ph) * 2 + 0][r], co, idx);
             o.y = epilogue(a, acc[(pd * 2 + ph) * 2 + 1][r], co, idx + 1);
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(256) void conv1_mfma_kernel(ConvArgs a) {
     for (int r = 0; r < 16; ++r) {
       const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
       if (co >= a.Cout) continue;
-      const long idx = ((long)n * a.Cout + co) * DHW + v;
+      const long idx = ((long)n * a.CoutTotal + a.co_off + co) * DHW + v;
       if (VEC) {
         if (v < DHW) {
           float4 o;
@@ -401,14 +402,14 @@ __global__ __launch_bounds__(256) void conv1_mfma_kernel(ConvArgs a) {
 // dst[tap][a][b] (a < Apad rows = contraction channels, b < Bpad = output channels, zero padded)
 // from a PyTorch weight: src_ab ? src[a][b][K] : src[b][a][K]; flip reverses the tap order.
 __global__ void prep_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int A, int Bn,
-                                   int Apad, int Bpad, int K, int src_ab, int flip) {
+                                   int Apad, int Bpad, int K, int src_ab, int flip, int Btotal, int b_off) {
   const int total = K * Apad * Bpad;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
     const int tap = idx / (Apad * Bpad), ai = (idx / Bpad) % Apad, bi = idx % Bpad;
     float v = 0.f;
     if (ai < A && bi < Bn) {
       const int st = flip ? K - 1 - tap : tap;
-      v = src_ab ? src[((long)ai * Bn + bi) * K + st] : src[((long)bi * A + ai) * K + st];
+      v = src_ab ? src[((long)ai * Btotal + b_off + bi) * K + st] : src[((long)(b_off + bi) * A + ai) * K + st];
     }
     dst[idx] = v;
   }
@@ -436,24 +437,27 @@ static int launch_conv3(ConvArgs& a, bool vec, hipStream_t stream) {
 }
 
 extern "C" int dca_conv3d_prep_weight(const float* w, float* wt, int A, int B, int Apad, int Bpad, int K,
-                                      int src_ab, int flip, hipStream_t stream) {
+                                      int src_ab, int flip, int Btotal, int b_off, hipStream_t stream) {
   DCA_REQUIRE(w && wt && A > 0 && B > 0 && Apad >= A && Bpad >= B && (K == 1 || K == 27));
+  DCA_REQUIRE(b_off >= 0 && b_off + B <= Btotal);
   const int total = K * Apad * Bpad;
   hipLaunchKernelGGL(prep_weight_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, w, wt, A, B, Apad, Bpad, K,
-                     src_ab, flip);
+                     src_ab, flip, Btotal, b_off);
   return dca_launch_status();
 }
 
 extern "C" int dca_conv3d_forward(const float* x, const float* x2, const float* wt, float* y, const float* scale,
                                   const float* shift, const float* res_pre, const float* res_post, float slope,
-                                  int N, int Cin, int C1, int Cout, int CinPad, int Di, int Hi, int Wi, int Do,
-                                  int Ho, int Wo, int ksize, int stride, int transposed, hipStream_t stream) {
+                                  int N, int Cin, int C1, int Cout, int CinPad, int CoutTotal, int co_off, int Di,
+                                  int Hi, int Wi, int Do, int Ho, int Wo, int ksize, int stride, int transposed,
+                                  hipStream_t stream) {
   DCA_REQUIRE(x && wt && y && N > 0 && Cin > 0 && Cout > 0 && CinPad >= Cin);
+  DCA_REQUIRE(co_off >= 0 && co_off + Cout <= CoutTotal);
   DCA_REQUIRE((scale == nullptr) == (shift == nullptr));
   ConvArgs a;
   a.x = x; a.x2 = x2; a.wt = wt; a.y = y; a.scale = scale; a.shift = shift;
   a.res_pre = res_pre; a.res_post = res_post; a.slope = slope;
-  a.N = N; a.Cin = Cin; a.Cout = Cout; a.CinPad = CinPad;
+  a.N = N; a.Cin = Cin; a.Cout = Cout; a.CinPad = CinPad; a.CoutTotal = CoutTotal; a.co_off = co_off;
   a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Do = Do; a.Ho = Ho; a.Wo = Wo;
   a.nTD = a.nTH = a.nTW = 1; a.xs_n = a.x2s_n = 0;
   const bool aligned = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)wt) & 15) == 0;

@@ -13,7 +13,7 @@
 #include "../../include/dca_hip.h"
 
 namespace {
-constexpr int NMAX = 32;
+constexpr int NMAX = 64;  // planes; the per-thread columns live in dynamic LDS (n * 256 floats)
 
 __device__ __forceinline__ void lin_src(int o, float rs, int n, int& i0, int& i1, float& l0, float& l1) {
   float src = rs * ((float)o + 0.5f) - 0.5f;
@@ -73,7 +73,7 @@ __device__ __forceinline__ Soft pixel_stats(const float* col, int n) {
 template <int S>
 __global__ __launch_bounds__(256) void up_softargmin_fwd_kernel(const float* __restrict__ logits,
                                                                 float* __restrict__ disp, int n, int hc, int wc) {
-  __shared__ float vs[NMAX * 256];
+  extern __shared__ float vs[];
   const int W = S * wc, H = S * hc;
   const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
   if (x >= W) return;
@@ -88,7 +88,7 @@ template <int S>
 __global__ __launch_bounds__(256) void up_softargmin_bwd1_kernel(const float* __restrict__ logits,
                                                                  const float* __restrict__ gdisp,
                                                                  float* __restrict__ g1, int n, int hc, int wc) {
-  __shared__ float vs[NMAX * 256];
+  extern __shared__ float vs[];
   const int W = S * wc, H = S * hc;
   const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
   if (x >= W) return;
@@ -156,27 +156,32 @@ __global__ void up_softargmin_bwd2_kernel(const float* __restrict__ g1, float* _
 
 extern "C" int dca_up_softargmin_fwd(const float* logits, float* disp, int B, int n, int hc, int wc, int scale,
                                      hipStream_t stream) {
-  DCA_REQUIRE(logits && disp && B > 0 && n >= 2 && n <= NMAX && hc > 0 && wc > 0 && (scale == 2 || scale == 8));
-  DCA_REQUIRE(scale * hc <= 65535 && B <= 65535);
+  DCA_REQUIRE(logits && disp && B > 0 && n >= 2 && n <= NMAX && hc > 0 && wc > 0);
+  DCA_REQUIRE((scale == 2 || scale == 4 || scale == 8) && scale * hc <= 65535 && B <= 65535);
   const dim3 grid(cdiv(scale * wc, 256), scale * hc, B);
-  if (scale == 8) hipLaunchKernelGGL(up_softargmin_fwd_kernel<8>, grid, dim3(256), 0, stream, logits, disp, n, hc, wc);
-  else hipLaunchKernelGGL(up_softargmin_fwd_kernel<2>, grid, dim3(256), 0, stream, logits, disp, n, hc, wc);
+  const size_t lds = (size_t)n * 256 * 4;
+#define LAUNCH(S) hipLaunchKernelGGL(up_softargmin_fwd_kernel<S>, grid, dim3(256), lds, stream, logits, disp, n, hc, wc)
+  if (scale == 8) LAUNCH(8);
+  else if (scale == 4) LAUNCH(4);
+  else LAUNCH(2);
+#undef LAUNCH
   return dca_launch_status();
 }
 
 extern "C" int dca_up_softargmin_bwd(const float* logits, const float* gdisp, float* g1, float* glogits, int B, int n,
                                      int hc, int wc, int scale, hipStream_t stream) {
   DCA_REQUIRE(logits && gdisp && g1 && glogits && B > 0 && n >= 2 && n <= NMAX && hc > 0 && wc > 0);
-  DCA_REQUIRE((scale == 2 || scale == 8) && scale * hc <= 65535 && B <= 65535);
+  DCA_REQUIRE((scale == 2 || scale == 4 || scale == 8) && scale * hc <= 65535 && B <= 65535);
   const dim3 grid(cdiv(scale * wc, 256), scale * hc, B);
   const long total = (long)B * n * hc * wc;
   const int g2 = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  if (scale == 8) {
-    hipLaunchKernelGGL(up_softargmin_bwd1_kernel<8>, grid, dim3(256), 0, stream, logits, gdisp, g1, n, hc, wc);
-    hipLaunchKernelGGL(up_softargmin_bwd2_kernel<8>, dim3(g2), dim3(256), 0, stream, g1, glogits, B, n, hc, wc);
-  } else {
-    hipLaunchKernelGGL(up_softargmin_bwd1_kernel<2>, grid, dim3(256), 0, stream, logits, gdisp, g1, n, hc, wc);
-    hipLaunchKernelGGL(up_softargmin_bwd2_kernel<2>, dim3(g2), dim3(256), 0, stream, g1, glogits, B, n, hc, wc);
-  }
+  const size_t lds = (size_t)n * 256 * 4;
+#define LAUNCH(S)                                                                                                   \
+  hipLaunchKernelGGL(up_softargmin_bwd1_kernel<S>, grid, dim3(256), lds, stream, logits, gdisp, g1, n, hc, wc);      \
+  hipLaunchKernelGGL(up_softargmin_bwd2_kernel<S>, dim3(g2), dim3(256), 0, stream, g1, glogits, B, n, hc, wc)
+  if (scale == 8) { LAUNCH(8); }
+  else if (scale == 4) { LAUNCH(4); }
+  else { LAUNCH(2); }
+#undef LAUNCH
   return dca_launch_status();
 }

@@ -152,6 +152,14 @@ class GwcNet(nn.Module):
         return pred4, r["prob_volume2"].squeeze(1)
 
 
+def __getattr__(name):
+    # the reference also defines `hourglass` (gwcnet_dca_g.py:69-106); it lives in models/gwcnet.py here
+    if name == "hourglass":
+        from .gwcnet import hourglass
+        return hourglass
+    raise AttributeError(name)
+
+
 def GwcNet_G(d):
     """factory expected by the reference's models/__init__.py:4-7 (present in gwcnet_dca{0,1,2}_g.py)"""
     return GwcNet(d, use_concat_volume=False)

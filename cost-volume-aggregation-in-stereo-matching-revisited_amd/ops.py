@@ -186,8 +186,8 @@ class _UpSoftArgmin(torch.autograd.Function):
 
 def up_softargmin(logits, scale):
     """(B,n,hc,wc) logits -> (B,1,s*hc,s*wc) expected disparity over s*n bins; falls back to the unfused kernels
-    for n > 32 or scales other than 2 / 8."""
-    if logits.shape[1] > 32 or logits.shape[1] < 2 or scale not in (2, 8):
+    for n > 64 or scales other than 2 / 4 / 8."""
+    if logits.shape[1] > 64 or logits.shape[1] < 2 or scale not in (2, 4, 8):
         return softargmin(trilinear_upsample(logits.unsqueeze(1), scale).squeeze(1))
     return _UpSoftArgmin.apply(logits, int(scale))
 
@@ -199,17 +199,25 @@ def _round_up(a, m):
     return (a + m - 1) // m * m
 
 
-def _prep_weight(w2d_src, A, B, K, src_ab, flip, ksize, stride, transposed):
-    """wt[tap][Apad][Bpad] for dca_conv3d_forward (padding rules of include/dca_hip.h)."""
+def _slice_width(ksize, stride, transposed, B):
+    """output channels one launch of dca_conv3d_forward produces (include/dca_hip.h)"""
+    if ksize == 1 or transposed:
+        return 32
+    return 32 if (stride == 1 and B <= 32) else 64
+
+
+def _prep_weight(w_src, A, B, K, src_ab, flip, ksize, stride, transposed, b_off=0, Bn=None):
+    """wt[tap][Apad][Bpad] for the output-channel slice [b_off, b_off+Bn) (padding rules of include/dca_hip.h)."""
+    Bn = B if Bn is None else Bn
     if ksize == 1:
         Apad = 32 if A <= 32 else 64
         Bpad = 32
     else:
         Apad = _round_up(A, 8)
-        Bpad = 32 if (transposed or (stride == 1 and B <= 32)) else 64
-    wt = torch.empty((K, Apad, Bpad), device=w2d_src.device, dtype=torch.float32)
-    _chk(_L().dca_conv3d_prep_weight(_ptr(w2d_src), _ptr(wt), A, B, Apad, Bpad, K, int(src_ab), int(flip), _stream()),
-         "dca_conv3d_prep_weight")
+        Bpad = 32 if (transposed or (stride == 1 and Bn <= 32)) else 64
+    wt = torch.empty((K, Apad, Bpad), device=w_src.device, dtype=torch.float32)
+    _chk(_L().dca_conv3d_prep_weight(_ptr(w_src), _ptr(wt), A, Bn, Apad, Bpad, K, int(src_ab), int(flip), B, b_off,
+                                     _stream()), "dca_conv3d_prep_weight")
     return wt, Apad
 
 
@@ -221,15 +229,35 @@ def _out_dims(dims, ksize, stride, transposed):
     return tuple((d + 1) // 2 for d in dims)
 
 
-def _conv_launch(x, x2, wt, CinPad, Cin, C1, Cout, ksize, stride, transposed, scale=None, shift=None, slope=1.0,
+def _conv_sliced(x, x2, w_src, A, B, K, src_ab, flip, ksize, stride, transposed, scale=None, shift=None, slope=1.0,
                  res_pre=None, res_post=None):
+    """y = conv(x [, x2]) with A contraction channels and B output channels, as ceil(B / slice) launches that each
+    write their channel slice of y (w_src is the PyTorch weight; src_ab / flip as in dca_conv3d_prep_weight)."""
     N = x.shape[0]
     Di, Hi, Wi = x.shape[2:]
     Do, Ho, Wo = _out_dims((Di, Hi, Wi), ksize, stride, transposed)
-    y = torch.empty((N, Cout, Do, Ho, Wo), device=x.device, dtype=torch.float32)
-    _chk(_L().dca_conv3d_forward(_ptr(x), _ptr(x2), _ptr(wt), _ptr(y), _ptr(scale), _ptr(shift), _ptr(res_pre),
-                                 _ptr(res_post), float(slope), N, Cin, C1, Cout, CinPad, Di, Hi, Wi, Do, Ho, Wo,
-                                 ksize, stride, int(transposed), _stream()), "dca_conv3d_forward")
+    y = torch.empty((N, B, Do, Ho, Wo), device=x.device, dtype=torch.float32)
+    C1 = x.shape[1]
+    width = _slice_width(ksize, stride, transposed, B)
+    lib = _L()
+    for b0 in range(0, B, width):
+        bn = min(width, B - b0)
+        wt, Apad = _prep_weight(w_src, A, B, K, src_ab, flip, ksize, stride, transposed, b0, bn)
+        _chk(lib.dca_conv3d_forward(_ptr(x), _ptr(x2), _ptr(wt), _ptr(y), _ptr(scale), _ptr(shift), _ptr(res_pre),
+                                    _ptr(res_post), float(slope), N, A, C1, bn, Apad, B, b0, Di, Hi, Wi, Do, Ho, Wo,
+                                    ksize, stride, int(transposed), _stream()), "dca_conv3d_forward")
+    return y
+
+
+def conv3d_prepared(x, wt, A, Apad, B, ksize, stride, transposed):
+    """single launch with an already laid-out weight (used by bench.py to time the bare kernel)"""
+    N = x.shape[0]
+    Di, Hi, Wi = x.shape[2:]
+    Do, Ho, Wo = _out_dims((Di, Hi, Wi), ksize, stride, transposed)
+    y = torch.empty((N, B, Do, Ho, Wo), device=x.device, dtype=torch.float32)
+    _chk(_L().dca_conv3d_forward(_ptr(x), None, _ptr(wt), _ptr(y), None, None, None, None, 1.0, N, A, A, B, Apad, B, 0,
+                                 Di, Hi, Wi, Do, Ho, Wo, ksize, stride, int(transposed), _stream()),
+         "dca_conv3d_forward")
     return y
 
 
@@ -239,14 +267,13 @@ def _conv_forward_impl(x, x2, weight, stride, transposed, scale=None, shift=None
     K = ksize ** 3
     if transposed:
         Cin, Cout = weight.shape[0], weight.shape[1]
-        wt, CinPad = _prep_weight(weight, Cin, Cout, K, 1, 0, ksize, stride, True)
+        src_ab = 1
     else:
         Cout, Cin = weight.shape[0], weight.shape[1]
-        wt, CinPad = _prep_weight(weight, Cin, Cout, K, 0, 0, ksize, stride, False)
-    C1 = x.shape[1]
-    assert C1 + (x2.shape[1] if x2 is not None else 0) == Cin, "conv3d: channel mismatch"
-    return _conv_launch(x, x2, wt, CinPad, Cin, C1, Cout, ksize, stride, transposed, scale, shift, slope, res_pre,
-                        res_post)
+        src_ab = 0
+    assert x.shape[1] + (x2.shape[1] if x2 is not None else 0) == Cin, "conv3d: channel mismatch"
+    return _conv_sliced(x, x2, weight, Cin, Cout, K, src_ab, 0, ksize, stride, transposed, scale, shift, slope,
+                        res_pre, res_post)
 
 
 def _wgrad(x, dy, dw_view_ptr_tensor, dst_offset, Cx, Cy, ksize, stride, s_cy, s_cx):
@@ -270,8 +297,7 @@ class _Conv3dC1(torch.autograd.Function):
         x, weight = _req(x, "conv3d"), _req(weight, "conv3d.weight")
         N, C, D, H, W = x.shape
         with torch.cuda.device_of(x):
-            wt, cpad = _prep_weight(weight, C, 27, 1, 1, 0, 1, 1, False)        # wt[ci][tap] = w[0, ci, tap]
-            T = _conv_launch(x, None, wt, cpad, C, C, 27, 1, 1, False)          # (N,27,D,H,W)
+            T = _conv_sliced(x, None, weight, C, 27, 1, 1, 0, 1, 1, False)      # wt[ci][tap] = w[0, ci, tap]; (N,27,D,H,W)
             y = torch.empty((N, 1, D, H, W), device=x.device, dtype=torch.float32)
             _chk(_L().dca_conv3d_c1_gather(_ptr(T), _ptr(y), N, D, H, W, _stream()), "dca_conv3d_c1_gather")
         ctx.save_for_backward(x, weight)
@@ -324,8 +350,7 @@ class _Conv3d(torch.autograd.Function):
             if transposed:
                 Cin, Cout = weight.shape[0], weight.shape[1]
                 if need_x:  # stride-2 conv of dy with Wt read as a Conv3d weight [Cin][Cout][K]
-                    wt, CinPad = _prep_weight(weight, Cout, Cin, K, 0, 0, 3, 2, False)
-                    gx = _conv_launch(dy, None, wt, CinPad, Cout, Cout, Cin, 3, 2, False)
+                    gx = _conv_sliced(dy, None, weight, Cout, Cin, K, 0, 0, 3, 2, False)
                 if need_w:
                     gw = torch.empty_like(weight)
                     _wgrad(dy, x, gw, 0, Cout, Cin, 3, 2, Cout * K, K)
@@ -333,11 +358,9 @@ class _Conv3d(torch.autograd.Function):
                 Cout, Cin = weight.shape[0], weight.shape[1]
                 if need_x:
                     if stride == 1:
-                        wt, CinPad = _prep_weight(weight, Cout, Cin, K, 1, 1, 3, 1, False)
-                        gx = _conv_launch(dy, None, wt, CinPad, Cout, Cout, Cin, 3, 1, False)
+                        gx = _conv_sliced(dy, None, weight, Cout, Cin, K, 1, 1, 3, 1, False)
                     else:
-                        wt, CinPad = _prep_weight(weight, Cout, Cin, K, 1, 0, 3, 2, True)
-                        gx = _conv_launch(dy, None, wt, CinPad, Cout, Cout, Cin, 3, 2, True)
+                        gx = _conv_sliced(dy, None, weight, Cout, Cin, K, 1, 0, 3, 2, True)
                         if gx.shape != x.shape:
                             raise RuntimeError("stride-2 conv backward needs even input dims")
                 if need_w:
@@ -347,17 +370,14 @@ class _Conv3d(torch.autograd.Function):
                 Cout, Cin = weight.shape[0], weight.shape[1]
                 w2 = weight.reshape(Cout, Cin)
                 C1 = x.shape[1]
+                if Cout not in (32, 64):
+                    raise RuntimeError("1x1x1 conv backward-data needs 32 or 64 output channels")
                 if need_x:
-                    halves = []
-                    for c0 in range(0, C1, 32):   # the 1x1 kernel produces <= 32 output channels per launch
-                        wa = w2[:, c0:min(C1, c0 + 32)].contiguous()
-                        wt, CinPad = _prep_weight(wa, Cout, wa.shape[1], 1, 1, 0, 1, 1, False)
-                        halves.append(_conv_launch(dy, None, wt, CinPad, Cout, Cout, wa.shape[1], 1, 1, False))
-                    gx = halves[0] if len(halves) == 1 else torch.cat(halves, 1)
+                    wa = w2[:, :C1].contiguous()
+                    gx = _conv_sliced(dy, None, wa, Cout, C1, 1, 1, 0, 1, 1, False)
                 if x2 is not None and need_x2:
                     wb = w2[:, C1:].contiguous()
-                    wt, CinPad = _prep_weight(wb, Cout, Cin - C1, 1, 1, 0, 1, 1, False)
-                    gx2 = _conv_launch(dy, None, wt, CinPad, Cout, Cout, Cin - C1, 1, 1, False)
+                    gx2 = _conv_sliced(dy, None, wb, Cout, Cin - C1, 1, 1, 0, 1, 1, False)
                 if need_w:
                     gw = torch.empty_like(weight)
                     _wgrad(x, dy, gw, 0, C1, Cout, 1, 1, Cin, 1)

@@ -45,7 +45,8 @@ int dca_softargmin_bwd(const float* aux, const float* g, float* gx, int B, int K
                        hipStream_t stream);
 
 /* Fused training head: disparity_regression(F.softmax(F.upsample(logits[:,None], scale_factor=(s,s,s),
- * mode='trilinear').squeeze(1), 1), s*n)  -- models/gwcnet_dca_g.py:261-264 (s = 8).  logits: (B,n,hc,wc), n <= 32;
+ * mode='trilinear').squeeze(1), 1), s*n)  -- models/gwcnet_dca_g.py:261-264 (s = 8) and the four heads of the baseline
+ * models/gwcnet.py:219-237 (s = 4).  s in {2,4,8}; logits: (B,n,hc,wc), n <= 64;
  * disp: (B,1,s*hc,s*wc).  bwd needs g1 = B*n*(s*hc)*(s*wc) floats of scratch. */
 int dca_up_softargmin_fwd(const float* logits, float* disp, int B, int n, int hc, int wc, int scale, hipStream_t stream);
 int dca_up_softargmin_bwd(const float* logits, const float* gdisp, float* g1, float* glogits, int B, int n, int hc,
@@ -62,22 +63,26 @@ int dca_up_softargmin_bwd(const float* logits, const float* gdisp, float* g1, fl
  *                                  weight used for its backward-data pass: A = Cout, B = Cin)
  *   flip = 1 reverses the taps (backward-data of a stride-1 convolution).
  * Padding rules: Apad = Cin rounded up to 8 (ksize 3) or exactly 32/64 (ksize 1);
- *                Bpad = 32 if (ksize 1 | transposed | (stride 1 & Cout <= 32)) else 64. */
+ *                Bpad = 32 if (ksize 1 | transposed | (stride 1 & Cout <= 32)) else 64.
+ * Btotal / b_off: the source has Btotal output channels of which this call lays out the slice [b_off, b_off+B)
+ * (layers with more output channels than one launch produces are run as several launches). */
 int dca_conv3d_prep_weight(const float* w, float* wt, int A, int B, int Apad, int Bpad, int K, int src_ab, int flip,
-                           hipStream_t stream);
+                           int Btotal, int b_off, hipStream_t stream);
 /* y = epilogue(conv(x [, x2], wt)).  ksize 3: pad 1, stride 1|2, or transposed (stride 2, pad 1,
  * output_padding 1).  ksize 1: Cin = 32 or 64; if x2 != NULL the input is cat([x, x2], dim=1) with 32
  * channels each (cva.py:69 without materialising the cat).  C1 = channels of x when x2 is given.
  * epilogue(v) = act(v*scale[co] + shift[co] + res_pre) + res_post, act(v) = v > 0 ? v : slope*v
  * (slope 1: none, 0: ReLU, 0.1: LeakyReLU); scale/shift/res_pre/res_post may be NULL.
+ * One launch produces Cout <= 64 (3x3x3 conv) or <= 32 (transposed, 1x1x1) channels and writes them at channel
+ * offset co_off of a CoutTotal-channel y (scale/shift/res_* are indexed in the full tensor).
  * Backward-data passes reuse this entry with re-laid-out weights:
  *   stride-1 conv   -> stride-1 conv,   src_ab = 1, flip = 1
  *   stride-2 conv   -> transposed conv, src_ab = 1, flip = 0
  *   transposed conv -> stride-2 conv,   src_ab = 0, flip = 0 */
 int dca_conv3d_forward(const float* x, const float* x2, const float* wt, float* y, const float* scale,
                        const float* shift, const float* res_pre, const float* res_post, float slope, int N, int Cin,
-                       int C1, int Cout, int CinPad, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int ksize,
-                       int stride, int transposed, hipStream_t stream);
+                       int C1, int Cout, int CinPad, int CoutTotal, int co_off, int Di, int Hi, int Wi, int Do, int Ho,
+                       int Wo, int ksize, int stride, int transposed, hipStream_t stream);
 /* dw[cy*s_cy + cx*s_cx + k] = sum_{n,o} dy[n,cy,o] x[n,cx,stride*o-1+k]  (ksize 3) / sum dy*x (ksize 1).
  * x: (N,Cx,Di,Hi,Wi), dy: (N,Cy,Do,Ho,Wo).  Conv3d: x = input, dy = grad of output, dw layout
  * (Cout,Cin,K).  ConvTranspose3d: x = grad of output (fine), dy = input (coarse), stride 2, dw layout

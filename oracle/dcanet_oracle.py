@@ -250,6 +250,44 @@ def hot_path(sd: SD, fL, fR, maxdisp: int, training: bool, num_groups: int = 40,
     return res
 
 
+def hot_path_baseline(sd: SD, fL, fR, maxdisp: int, num_groups: int = 40):
+    """Training branch of the baseline gwcnet.GwcNet.forward (models/gwcnet.py:194-238) from the 1/4-res features:
+    returns [pred0..pred3], each (B,1,4h,4w).  BN layers run in training mode (batch statistics)."""
+    d = maxdisp // 4
+    vol = build_gwc_volume(fL, fR, d, num_groups)
+    cost0 = dres0(sd, "dres0", vol, True)
+    cost0 = dres1(sd, "dres1", cost0, True) + cost0
+    out1 = hourglass(sd, "dres2", cost0, True)
+    out2 = hourglass(sd, "dres3", out1, True)
+    out3 = hourglass(sd, "dres4", out2, True)
+    preds = []
+    for i, t in enumerate((cost0, out1, out2, out3)):
+        c = classif(sd, f"classif{i}", t, True)
+        c = F.interpolate(c, size=[maxdisp, 4 * fL.shape[2], 4 * fL.shape[3]], mode="trilinear").squeeze(1)
+        preds.append(disparity_regression(F.softmax(c, dim=1), maxdisp))
+    return preds
+
+
+def baseline_shapes(num_groups: int = 40):
+    s = {}
+
+    def bn(p, c):
+        s[p + ".weight"] = (c,); s[p + ".bias"] = (c,)
+        s[p + ".running_mean"] = (c,); s[p + ".running_var"] = (c,)
+        s[p + ".num_batches_tracked"] = ()
+
+    def convbn(p, ci, co, k):
+        s[p + ".0.weight"] = (co, ci, k, k, k); bn(p + ".1", co)
+
+    convbn("dres0.0", num_groups, 32, 3); convbn("dres0.2", 32, 32, 3)
+    convbn("dres1.0", 32, 32, 3); convbn("dres1.2", 32, 32, 3)
+    for i in range(4):
+        convbn(f"classif{i}.0", 32, 32, 3); s[f"classif{i}.2.weight"] = (1, 32, 3, 3, 3)
+    for name in ("dres2", "dres3", "dres4"):
+        s.update(hourglass_shapes(name, 32))
+    return s
+
+
 # --------------------------------------------------------------------------------------
 # Deterministic, well-conditioned test weights (SURVEY Appendix D)
 # --------------------------------------------------------------------------------------

@@ -214,6 +214,36 @@ def gen_hot_path():
                 npz(stem, pred4_q=pred4, prob_volume2=prob2, gfL=g[0][:, ::16], gfR=g[1][:, ::16])
 
 
+def gen_baseline():
+    """Baseline gwcnet.GwcNet (3 stacked hourglasses), training branch, from the 1/4-res features."""
+    m = ref_gwc.GwcNet(32, use_concat_volume=False)
+    m.feature_extraction = _FeatStub(False)
+    load_seeded(m)
+    m.train()
+    fL = seeded_tensor("base.fL", (2, 320, 16, 32)).requires_grad_()
+    fR = seeded_tensor("base.fR", (2, 320, 16, 32)).requires_grad_()
+    left = torch.zeros(2, 3, 64, 128)       # only its size is read (gwcnet.py:219)
+    m.feature_extraction = _FeatByShape(fL, fR)
+    preds = m(left, left.clone() + 1, None)
+    params = [m.dres2.conv5[0].weight, m.dres3.conv3[0][0].weight, m.dres4.redir2[0].weight, m.dres2.conv4[0][1].weight]
+    g = grads_of(preds, [f"base.g{i}" for i in range(4)], [fL, fR] + params)
+    npz("baseline_g_train", pred0=preds[0], pred1=preds[1], pred2=preds[2], pred3=preds[3], gfL=g[0][:, ::16],
+        gfR=g[1][:, ::16], g_d2c5_w=g[2], g_d3c3_w=g[3], g_d4r2_w=g[4], g_d2c4_bnw=g[5])
+
+
+class _FeatByShape(nn.Module):
+    """returns the prepared 1/4-res features: first call -> left, second call -> right"""
+
+    def __init__(self, fL, fR):
+        super().__init__()
+        self.feats, self.i = [fL, fR], 0
+
+    def forward(self, x):
+        f = self.feats[self.i % 2]
+        self.i += 1
+        return {"gwc_feature": f}
+
+
 def gen_losses():
     import models.loss as ref_loss
     gt = torch.rand(2, 1, 32, 64, generator=torch.Generator().manual_seed(7)) * 40.0 - 2.0   # some invalid (<0, >=32)
@@ -244,7 +274,7 @@ def gen_state_dict_keys():
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["volumes", "inject", "attention", "cva", "magg", "hot", "keys", "losses"]
+    which = sys.argv[1:] or ["volumes", "inject", "attention", "cva", "magg", "hot", "keys", "losses", "baseline"]
     with torch.enable_grad():
         if "volumes" in which: gen_volumes()
         if "inject" in which: gen_context_inject()
@@ -254,3 +284,4 @@ if __name__ == "__main__":
         if "hot" in which: gen_hot_path()
         if "keys" in which: gen_state_dict_keys()
         if "losses" in which: gen_losses()
+        if "baseline" in which: gen_baseline()

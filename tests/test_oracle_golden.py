@@ -210,3 +210,21 @@ def test_hot_path(golden, variant, training):
         close(r["prob_volume2"].squeeze(1), g["prob_volume2"], 2e-5, "prob_volume2")
         gr = grads_of([r["pred4_q"]], ["hot.g_eval"], [fL, fR])
         close(gr[0][:, ::16], g["gfL"], 2e-4); close(gr[1][:, ::16], g["gfR"], 2e-4)
+
+
+def test_baseline_gwcnet(golden):
+    """baseline gwcnet.GwcNet training branch (three stacked hourglasses), reference models/gwcnet.py:194-238"""
+    g = golden("baseline_g_train")
+    sd = O.seeded_state_dict(O.baseline_shapes())
+    names = ["dres2.conv5.0.weight", "dres3.conv3.0.0.weight", "dres4.redir2.0.weight", "dres2.conv4.0.1.weight"]
+    for k in names:
+        sd[k].requires_grad_()
+    fL = seeded_tensor("base.fL", (2, 320, 16, 32)).requires_grad_()
+    fR = seeded_tensor("base.fR", (2, 320, 16, 32)).requires_grad_()
+    preds = O.hot_path_baseline(sd, fL, fR, 32)
+    for i, p in enumerate(preds):
+        close(p, g[f"pred{i}"], 2e-5, f"pred{i}")
+    gr = grads_of(preds, [f"base.g{i}" for i in range(4)], [fL, fR] + [sd[k] for k in names])
+    close_l2(gr[0][:, ::16], g["gfL"], 2e-3, "gfL"); close_l2(gr[1][:, ::16], g["gfR"], 2e-3, "gfR")
+    for got, name in zip(gr[2:], ["g_d2c5_w", "g_d3c3_w", "g_d4r2_w", "g_d2c4_bnw"]):
+        close_l2(thin(got), g[name], 2e-3, name)
