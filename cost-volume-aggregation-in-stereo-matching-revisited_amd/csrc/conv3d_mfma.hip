@@ -317,9 +317,14 @@ __global__ __launch_bounds__(256, 2) void deconv3_mfma_kernel(ConvArgs a) {
           const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
           if (co < a.Cout) {
             const long idx = ((((long)n * a.CoutTotal + a.co_off + co) * a.Do + d) * a.Ho + h) * a.Wo + 2 * mw;
-            float2 o;
-            o.x = epilogue(a, acc[(pd * 2 + ph) * 2 + 0][r], co, idx);
-            o.y = epilogue(a, acc[(pd * 2 + ph) * 2 + 1][r], co, idx + 1);
+            float2 o = make_float2(acc[(pd * 2 + ph) * 2 + 0][r], acc[(pd * 2 + ph) * 2 + 1][r]);
+            if (a.scale) {
+              const float sc = a.scale[a.co_off + co], sh = a.shift[a.co_off + co];
+              o.x = o.x * sc + sh; o.y = o.y * sc + sh;
+            }
+            if (a.res_pre) { const float2 rp = *(const float2*)(a.res_pre + idx); o.x += rp.x; o.y += rp.y; }
+            o.x = act_apply(o.x, a.slope); o.y = act_apply(o.y, a.slope);
+            if (a.res_post) { const float2 rq = *(const float2*)(a.res_post + idx); o.x += rq.x; o.y += rq.y; }
             *(float2*)(a.y + idx) = o;
           }
         }

@@ -29,8 +29,11 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
 
 
 class FlatGradBucket:
-    """Owns one contiguous fp32 buffer; parameter .grad tensors are views into it, so the all-reduce needs
-    no gather/scatter copies (18.3 MB for GwcNet-G: one message per step)."""
+    """One contiguous fp32 buffer for all gradients (18.3 MB for GwcNet-G: one all-reduce message per step).
+
+    Per step:  `zero()` drops the old .grad tensors so autograd ASSIGNS fresh gradients (no `grad += g` kernel per
+    parameter); `all_reduce_mean()` gathers them into the flat buffer with one batched copy, all-reduces it, and
+    re-points every parameter's .grad at its slice of the buffer (views, no scatter copies)."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter]):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
@@ -38,15 +41,33 @@ class FlatGradBucket:
         dev = self.params[0].device
         self.numel = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(self.numel, device=dev, dtype=torch.float32)
+        self.views: List[torch.Tensor] = []
         off = 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
+        self.zero()
 
     def zero(self):
-        self.flat.zero_()
+        for p in self.params:
+            p.grad = None
+
+    def gather(self):
+        """copies the freshly assigned .grad tensors into the flat buffer (parameters without a gradient -> 0)"""
+        src, dst = [], []
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                src.append(p.grad)
+                dst.append(v)
+        if src:
+            torch._foreach_copy_(dst, src)
+        for p, v in zip(self.params, self.views):
+            p.grad = v
 
     def all_reduce_mean(self):
+        self.gather()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.div_(dist.get_world_size())
