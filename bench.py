@@ -165,8 +165,16 @@ def main():
     ap.add_argument("--mode", choices=["fwdbwd", "fwd"], default="fwdbwd")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=34)
+    ap.add_argument("--graph", action="store_true", help="fwd mode: replay the eval hot path as one hipGraph")
+    ap.add_argument("--shape", default=None, help="HxWxD of a secondary workload (e.g. 384x1248x192 KITTI, "
+                                                  "256x512x64 plumbing); default = BASELINE's 544x960x192")
     args = ap.parse_args()
 
+    global H_IMG, W_IMG, MAXDISP
+    if args.shape:
+        H_IMG, W_IMG, MAXDISP = (int(v) for v in args.shape.lower().split("x"))
+        assert H_IMG % 8 == 0 and W_IMG % 8 == 0 and MAXDISP % 8 == 0
+        args.no_cpu_baseline = True
     from dcanet_amd.parallel import FlatGradBucket, init_from_env
     rank, local, world = init_from_env()
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
@@ -186,7 +194,15 @@ def main():
         step = lambda: train_step(m, fL, fR, guid, gt, bucket, opt)
     else:
         m.eval()
-        step = lambda: eval_step(m, fL, fR, guid)
+        if args.graph:
+            from dcanet_amd.graph import GraphedHotPath
+            graphed = GraphedHotPath(m, fL, fR)
+
+            def step():
+                with torch.no_grad():
+                    return m.prop(guid, graphed(fL, fR)["pred4_q"])
+        else:
+            step = lambda: eval_step(m, fL, fR, guid)
 
     for _ in range(args.warmup):
         step()
@@ -211,18 +227,18 @@ def main():
     if rank == 0:
         volumes = args.steps * args.batch * world
         line = {
-            "metric": "cost-volumes/sec (fwd+bwd) at 544x960 D=192" if args.mode == "fwdbwd"
-            else "cost-volumes/sec (fwd only) at 544x960 D=192",
+            "metric": f"cost-volumes/sec (fwd+bwd) at {H_IMG}x{W_IMG} D={MAXDISP}" if args.mode == "fwdbwd"
+            else f"cost-volumes/sec (fwd only) at {H_IMG}x{W_IMG} D={MAXDISP}",
             "value": round(volumes / dt, 4), "unit": "cost-volumes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "gwcnet_dca_g (GwcNet-G + 3 DCA blocks) hot path from 1/4-res features, "
-                                   "544x960 D=192, " + ("train step: fwd(all heads)+focal/model loss+bwd+allreduce+Adam"
+                                   f"{H_IMG}x{W_IMG} D={MAXDISP}, " + ("train step: fwd(all heads)+focal/model loss+bwd+allreduce+Adam"
                                                         if args.mode == "fwdbwd" else "eval forward"),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "mode": args.mode},
+                       "mode": args.mode, "hipgraph": bool(args.graph)},
         }
-        roof = kernel_roofline(device)
+        roof = kernel_roofline(device) if not args.shape else {}
         names = list(roof)
         # HBM bytes per launch from the PMC passes committed under profiles/ (cannot be collected inside this run)
         try:
@@ -232,8 +248,9 @@ def main():
                 roof[n]["algorithmic_bytes"] = pmc[key]["algorithmic_bytes"]
         except (OSError, KeyError, ValueError):
             pass
-        line["roofline"] = dict(roof[names[0]], kernel=names[0])
-        line["roofline_other"] = {n: roof[n] for n in names[1:]}
+        if names:
+            line["roofline"] = dict(roof[names[0]], kernel=names[0])
+            line["roofline_other"] = {n: roof[n] for n in names[1:]}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(m, args.mode, args.cpu_rows)
         print(json.dumps(line), flush=True)

@@ -522,3 +522,23 @@ def test_golden_baseline_gwcnet(golden):
     close_l2(gr[0][:, ::16], g["gfL"], 1.5e-2, "gfL"); close_l2(gr[1][:, ::16], g["gfR"], 1.5e-2, "gfR")
     for got, name in zip(gr[2:], ["g_d2c5_w", "g_d3c3_w", "g_d4r2_w", "g_d2c4_bnw"]):
         close_l2(thin(got), g[name], 1.5e-2, name)
+
+
+# ------------------------------------------------------------------------------------- hipGraph replay (config 5)
+def test_graph_replay_matches_eager():
+    """the eval hot path captures into one hipGraph (no host syncs on the path); replays match eager runs to the
+    run-to-run noise of the float atomics in the context-injection class sums"""
+    from dcanet_amd.graph import GraphedHotPath
+    from dcanet_amd.models.gwcnet_dca_g import GwcNet
+    m = load_seeded(GwcNet(64, use_concat_volume=False)).to(DEV).eval()
+    fL, fR = seeded_tensor("gr.fL", (1, 320, 24, 40)).to(DEV), seeded_tensor("gr.fR", (1, 320, 24, 40)).to(DEV)
+    g = GraphedHotPath(m, fL, fR)
+    fL2, fR2 = seeded_tensor("gr.fL2", (1, 320, 24, 40)).to(DEV), seeded_tensor("gr.fR2", (1, 320, 24, 40)).to(DEV)
+    with torch.no_grad():
+        want = m.hot_path(fL2, fR2)["pred4_q"].clone()
+    got = g(fL2, fR2)["pred4_q"]
+    close(got, want, 1e-5, "replay on new inputs")
+    got1 = g(fL, fR)["pred4_q"].clone()
+    with torch.no_grad():
+        close(got1, m.hot_path(fL, fR)["pred4_q"], 1e-5, "replay on the captured inputs")
+        assert (got1 - want).abs().max() > 1e-2, "degenerate: outputs do not depend on the inputs"
