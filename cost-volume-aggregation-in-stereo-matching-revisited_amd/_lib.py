@@ -34,8 +34,8 @@ SIGNATURES = {
     "dca_avgpool3d_bwd": (_i, [_p, _p, _l, _i, _i, _i, _p]),
     "dca_trilinear_fwd": (_i, [_p, _p, _l, _i, _i, _i, _i, _p]),
     "dca_trilinear_bwd": (_i, [_p, _p, _l, _i, _i, _i, _i, _p]),
-    "dca_context_inject_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _l, _p]),
-    "dca_context_inject_bwd": (_i, [_p] * 11 + [_i, _i, _i, _l, _p]),
+    "dca_context_inject_fwd": (_i, [_p] * 8 + [_i, _i, _i, _l, _p]),
+    "dca_context_inject_bwd": (_i, [_p] * 12 + [_i, _i, _i, _l, _p]),
     "dca_disp_attention_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _l, _p]),
     "dca_disp_attention_bwd": (_i, [_p] * 7 + [_i, _i, _i, _l, _p]),
 }

@@ -15,15 +15,39 @@
 // ---------------------------------------------------------------------------------------------
 // context injection, forward
 // ---------------------------------------------------------------------------------------------
-// per pixel: k*, e = exp(p[k*] - 1), pm = p[k*]; denom[b][k] += e over pixels with k* = k
+// Deterministic per-class sums: every wave reduces (kstar == k ? val : 0) with a fixed shuffle tree, the 4 wave
+// results are added in order, each workgroup writes its partial row part[(b*nblk + blk)*n + k] and a second kernel
+// adds the rows in block order.  (Float atomics here made the whole network non-reproducible at the 1e-7 level,
+// which can flip an arg-max further down -- a discontinuity of the reference's algorithm itself.)
+__device__ __forceinline__ void class_partials(float val, int kb, bool valid, int n, float* red /*[4][n]*/,
+                                               float* __restrict__ part_row) {
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  for (int k = 0; k < n; ++k) {
+    const float s = wave_sum((valid && kb == k) ? val : 0.f);
+    if (lane == 0) red[wv * n + k] = s;
+  }
+  __syncthreads();
+  for (int k = tid; k < n; k += 256) part_row[k] = (red[k] + red[n + k]) + (red[2 * n + k] + red[3 * n + k]);
+}
+
+__global__ void class_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk, int n, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * n) return;
+  const int b = i / n, k = i % n;
+  float s = 0.f;
+  for (int j = 0; j < nblk; ++j) s += part[((long)b * nblk + j) * n + k];
+  out[i] = s;
+}
+
+// per pixel: k*, e = exp(p[k*] - 1), pm = p[k*]; part[b][blk][k] = sum of e over this block's pixels with k* = k
 __global__ __launch_bounds__(256) void ctx_stats_kernel(const float* __restrict__ preds, int* __restrict__ kstar,
                                                         float* __restrict__ e_out, float* __restrict__ pm_out,
-                                                        float* __restrict__ denom, int n, long HW) {
-  extern __shared__ float cls[];
+                                                        float* __restrict__ part, int n, long HW) {
+  extern __shared__ float red[];
   const int b = blockIdx.y, tid = threadIdx.x;
-  for (int k = tid; k < n; k += 256) cls[k] = 0.f;
-  __syncthreads();
   const long pix = (long)blockIdx.x * 256 + tid;
+  float e = 0.f;
+  int kb = -1;
   if (pix < HW) {
     const float* lp = preds + (long)b * n * HW + pix;
     float m = -INFINITY;
@@ -31,20 +55,17 @@ __global__ __launch_bounds__(256) void ctx_stats_kernel(const float* __restrict_
     float s = 0.f;
     for (int k = 0; k < n; ++k) s += expf(lp[k * HW] - m);
     float best = -1.f;
-    int kb = 0;
+    kb = 0;
     for (int k = 0; k < n; ++k) {
       const float p = expf(lp[k * HW] - m) / s;
       if (p > best) { best = p; kb = k; }   // first maximum on ties (argmax)
     }
-    const float e = expf(best - 1.0f);
+    e = expf(best - 1.0f);
     kstar[(long)b * HW + pix] = kb;
     e_out[(long)b * HW + pix] = e;
     pm_out[(long)b * HW + pix] = best;
-    atomicAdd(&cls[kb], e);
   }
-  __syncthreads();
-  for (int k = tid; k < n; k += 256)
-    if (cls[k] != 0.f) atomicAdd(&denom[b * n + k], cls[k]);
+  class_partials(e, kb, pix < HW, n, red, part + ((long)b * gridDim.x + blockIdx.x) * n);
 }
 
 // out[b,c,k,pix] = in[b,c,k,pix] * (1 + [k == k*] e/denom[b,k*])   (forward: in = x; backward: in = dkey)
@@ -66,31 +87,28 @@ __global__ void ctx_scale_kernel(const float* __restrict__ in, const int* __rest
 // ---------------------------------------------------------------------------------------------
 // context injection, backward
 // ---------------------------------------------------------------------------------------------
-// dw[pix] = sum_c dkey[c,k*,pix] x[c,k*,pix];  T[b][k] += w*dw over the class
+// dw[pix] = sum_c dkey[c,k*,pix] x[c,k*,pix];  part[b][blk][k] = sum of w*dw over this block's pixels of class k
 __global__ __launch_bounds__(256) void ctx_bwd_reduce_kernel(const float* __restrict__ dkey,
                                                              const float* __restrict__ x,
                                                              const int* __restrict__ kstar,
                                                              const float* __restrict__ e,
                                                              const float* __restrict__ denom,
-                                                             float* __restrict__ dw, float* __restrict__ T, int C,
+                                                             float* __restrict__ dw, float* __restrict__ part, int C,
                                                              int n, long HW) {
-  extern __shared__ float cls[];
+  extern __shared__ float red[];
   const int b = blockIdx.y, tid = threadIdx.x;
-  for (int k = tid; k < n; k += 256) cls[k] = 0.f;
-  __syncthreads();
   const long pix = (long)blockIdx.x * 256 + tid;
+  float val = 0.f;
+  int ks = -1;
   if (pix < HW) {
-    const int ks = kstar[(long)b * HW + pix];
+    ks = kstar[(long)b * HW + pix];
     const long base = ((long)b * C * n + ks) * HW + pix;
     float s = 0.f;
     for (int c = 0; c < C; ++c) s += dkey[base + (long)c * n * HW] * x[base + (long)c * n * HW];
     dw[(long)b * HW + pix] = s;
-    const float w = e[(long)b * HW + pix] / denom[b * n + ks];
-    atomicAdd(&cls[ks], w * s);
+    val = e[(long)b * HW + pix] / denom[b * n + ks] * s;
   }
-  __syncthreads();
-  for (int k = tid; k < n; k += 256)
-    if (cls[k] != 0.f) atomicAdd(&T[b * n + k], cls[k]);
+  class_partials(val, ks, pix < HW, n, red, part + ((long)b * gridDim.x + blockIdx.x) * n);
 }
 
 // dpreds[b,k,pix] = dm * pm * ([k==k*] - p_k),  dm = w (dw - T[b,k*])
@@ -298,30 +316,33 @@ static int ew_grid(long total) {
   return (int)(g < 8192 ? (g > 0 ? g : 1) : 8192);
 }
 
-// x, key: (B,C,n,H,W); preds: (B,n,H,W); outputs kstar (B,HW) int32, e/pm (B,HW), denom (B,n)
+// x, key: (B,C,n,H,W); preds: (B,n,H,W); outputs kstar (B,HW) int32, e/pm (B,HW), denom (B,n).
+// part: scratch of B * ceil(HW/256) * n floats.
 extern "C" int dca_context_inject_fwd(const float* x, const float* preds, float* key, int* kstar, float* e, float* pm,
-                                      float* denom, int B, int C, int n, long HW, hipStream_t stream) {
-  DCA_REQUIRE(x && preds && key && kstar && e && pm && denom && B > 0 && C > 0 && n > 0 && HW > 0 && B <= 65535);
-  hipError_t err = hipMemsetAsync(denom, 0, (size_t)B * n * sizeof(float), stream);
-  if (err != hipSuccess) return (int)err;
-  hipLaunchKernelGGL(ctx_stats_kernel, dim3(cdiv(HW, 256), B), dim3(256), n * sizeof(float), stream, preds, kstar, e,
-                     pm, denom, n, HW);
+                                      float* denom, float* part, int B, int C, int n, long HW, hipStream_t stream) {
+  DCA_REQUIRE(x && preds && key && kstar && e && pm && denom && part && B > 0 && C > 0 && n > 0 && HW > 0);
+  DCA_REQUIRE(B <= 65535);
+  const int nblk = cdiv(HW, 256);
+  hipLaunchKernelGGL(ctx_stats_kernel, dim3(nblk, B), dim3(256), 4 * n * sizeof(float), stream, preds, kstar, e, pm,
+                     part, n, HW);
+  hipLaunchKernelGGL(class_sum_kernel, dim3(cdiv((long)B * n, 64)), dim3(64), 0, stream, part, denom, nblk, n, B);
   const long total = (long)B * C * n * HW;
   hipLaunchKernelGGL(ctx_scale_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, x, kstar, e, denom, key, C, n, HW,
                      total);
   return dca_launch_status();
 }
 
-// dkey -> dx (B,C,n,HW) and dpreds (B,n,HW); scratch dw (B,HW), T (B,n)
+// dkey -> dx (B,C,n,HW) and dpreds (B,n,HW); scratch dw (B,HW), T (B,n), part (B * ceil(HW/256) * n)
 extern "C" int dca_context_inject_bwd(const float* dkey, const float* x, const float* preds, const int* kstar,
                                       const float* e, const float* pm, const float* denom, float* dx, float* dpreds,
-                                      float* dw, float* T, int B, int C, int n, long HW, hipStream_t stream) {
-  DCA_REQUIRE(dkey && x && preds && kstar && e && pm && denom && dx && dpreds && dw && T);
+                                      float* dw, float* T, float* part, int B, int C, int n, long HW,
+                                      hipStream_t stream) {
+  DCA_REQUIRE(dkey && x && preds && kstar && e && pm && denom && dx && dpreds && dw && T && part);
   DCA_REQUIRE(B > 0 && C > 0 && n > 0 && HW > 0 && B <= 65535);
-  hipError_t err = hipMemsetAsync(T, 0, (size_t)B * n * sizeof(float), stream);
-  if (err != hipSuccess) return (int)err;
-  hipLaunchKernelGGL(ctx_bwd_reduce_kernel, dim3(cdiv(HW, 256), B), dim3(256), n * sizeof(float), stream, dkey, x,
-                     kstar, e, denom, dw, T, C, n, HW);
+  const int nblk = cdiv(HW, 256);
+  hipLaunchKernelGGL(ctx_bwd_reduce_kernel, dim3(nblk, B), dim3(256), 4 * n * sizeof(float), stream, dkey, x, kstar, e,
+                     denom, dw, part, C, n, HW);
+  hipLaunchKernelGGL(class_sum_kernel, dim3(cdiv((long)B * n, 64)), dim3(64), 0, stream, part, T, nblk, n, B);
   hipLaunchKernelGGL(ctx_bwd_preds_kernel, dim3(ew_grid((long)B * HW)), dim3(256), 0, stream, preds, kstar, e, pm,
                      denom, dw, T, dpreds, n, HW, (long)B * HW);
   const long total = (long)B * C * n * HW;

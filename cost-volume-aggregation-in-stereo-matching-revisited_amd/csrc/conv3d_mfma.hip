@@ -509,11 +509,16 @@ extern "C" int dca_conv3d_forward(const float* x, const float* x2, const float* 
                         cdiv(Wo, shapes[i].tw) * shapes[i].tw;
       if (best_cost < 0 || cost < best_cost) { best = i; best_cost = cost; }
     }
+    // small volumes: fewer than two workgroups per CU with 512-voxel tiles -> 128-voxel tiles (4x the workgroups)
+    const long nblk = (long)N * cdiv(Do, shapes[best].td) * cdiv(Ho, shapes[best].th) * cdiv(Wo, shapes[best].tw);
+    const bool small = nblk < 512;
     if (Cout <= 32) {
+      if (small) return launch_conv3<1, 1, 8, 2, 4, 16>(a, vec, stream);
       if (best == 0) return launch_conv3<1, 1, 8, 2, 8, 32>(a, vec, stream);
       if (best == 1) return launch_conv3<1, 1, 8, 4, 4, 32>(a, vec, stream);
       return launch_conv3<1, 1, 8, 4, 8, 16>(a, vec, stream);
     }
+    if (small) return launch_conv3<1, 2, 4, 2, 4, 16>(a, vec, stream);
     if (best == 0) return launch_conv3<1, 2, 4, 2, 8, 32>(a, vec, stream);
     if (best == 1) return launch_conv3<1, 2, 4, 4, 4, 32>(a, vec, stream);
     return launch_conv3<1, 2, 4, 4, 8, 16>(a, vec, stream);

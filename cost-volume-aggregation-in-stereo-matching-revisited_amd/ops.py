@@ -574,9 +574,10 @@ class _ContextInject(torch.autograd.Function):
         e = torch.empty((B, HW), device=x.device, dtype=torch.float32)
         pm = torch.empty_like(e)
         denom = torch.empty((B, n), device=x.device, dtype=torch.float32)
+        part = torch.empty((B * ((HW + 255) // 256) * n,), device=x.device, dtype=torch.float32)
         with torch.cuda.device_of(x):
             _chk(_L().dca_context_inject_fwd(_ptr(x), _ptr(preds), _ptr(key), _ptr(kstar), _ptr(e), _ptr(pm),
-                                             _ptr(denom), B, C, n, HW, _stream()), "dca_context_inject_fwd")
+                                             _ptr(denom), _ptr(part), B, C, n, HW, _stream()), "dca_context_inject_fwd")
         ctx.save_for_backward(x, preds, kstar, e, pm, denom)
         ctx.mark_non_differentiable(kstar)
         return key, kstar
@@ -590,10 +591,11 @@ class _ContextInject(torch.autograd.Function):
         dx, dpreds = torch.empty_like(x), torch.empty_like(preds)
         dw = torch.empty_like(e)
         T = torch.empty_like(denom)
+        part = torch.empty((B * ((HW + 255) // 256) * n,), device=x.device, dtype=torch.float32)
         with torch.cuda.device_of(x):
             _chk(_L().dca_context_inject_bwd(_ptr(dkey), _ptr(x), _ptr(preds), _ptr(kstar), _ptr(e), _ptr(pm),
-                                             _ptr(denom), _ptr(dx), _ptr(dpreds), _ptr(dw), _ptr(T), B, C, n, HW,
-                                             _stream()), "dca_context_inject_bwd")
+                                             _ptr(denom), _ptr(dx), _ptr(dpreds), _ptr(dw), _ptr(T), _ptr(part), B, C,
+                                             n, HW, _stream()), "dca_context_inject_bwd")
         return dx, dpreds
 
 

@@ -133,12 +133,13 @@ int dca_trilinear_bwd(const float* gy, float* gx, long NC, int Di, int Hi, int W
 
 /* ---- homogeneous-region context injection -- SemanticLevelContext.forward, semantic_level.py:96-126 ---
  * x,key: (B,C,n,HW); preds: (B,n,HW) logits.  key = feats_sl + x.  Side outputs (saved for backward):
- * kstar (B,HW) int32 argmax class, e (B,HW), pm (B,HW) = p[k*], denom (B,n). */
+ * kstar (B,HW) int32 argmax class, e (B,HW), pm (B,HW) = p[k*], denom (B,n).  part: scratch of
+ * B*ceil(HW/256)*n floats (per-workgroup class sums, added in a fixed order: bitwise reproducible). */
 int dca_context_inject_fwd(const float* x, const float* preds, float* key, int* kstar, float* e, float* pm,
-                           float* denom, int B, int C, int n, long HW, hipStream_t stream);
+                           float* denom, float* part, int B, int C, int n, long HW, hipStream_t stream);
 int dca_context_inject_bwd(const float* dkey, const float* x, const float* preds, const int* kstar, const float* e,
-                           const float* pm, const float* denom, float* dx, float* dpreds, float* dw, float* T, int B,
-                           int C, int n, long HW, hipStream_t stream);
+                           const float* pm, const float* denom, float* dx, float* dpreds, float* dw, float* T,
+                           float* part, int B, int C, int n, long HW, hipStream_t stream);
 
 /* ---- per-pixel disparity attention core -- SelfAttentionBlock.forward, SelfAttention_bn.py:70-94 ------
  * q,k,v,out: (B,C,n,HW), heads of 8 channels, softmax(q k^T / sqrt(8)) v over the n bins (n <= 32). */
