@@ -245,26 +245,60 @@ __global__ __launch_bounds__(256, 2) void deconv3_mfma_kernel(ConvArgs a) {
     for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
   const int boff = ((half * ID + mdl) * IH + mhl) * IWP + 4 + l31;
 
+  // software pipeline (aligned inputs): next chunk's global loads are in flight during the MFMA block
+  constexpr int WQ = CK * CO / 4;
+  constexpr int KX = (ROWS * 8 + 255) / 256, KH = (ROWS + 255) / 256, KW = (27 * WQ + 255) / 256;
+  float4 rx[VEC ? KX : 1], rw[VEC ? KW : 1];
+  float rh[VEC ? KH : 1];
+  auto load_regs = [&](int ci0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < KX; ++k) {
+      const int it = tid + 256 * k;
+      const int row = it >> 3, q = it & 7;
+      const int c = row / 9, rem = row % 9, id = rem / 3, ih = rem % 3;
+      const int ci = ci0 + c, di = md0 + id, hi = mh0 + ih, wi = mw0 + 4 * q;
+      rx[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (it < ROWS * 8 && ci < a.Cin && di < a.Di && hi < a.Hi && wi < a.Wi)
+        rx[k] = *(const float4*)(a.x + ((((long)n * a.Cin + ci) * a.Di + di) * a.Hi + hi) * a.Wi + wi);
+    }
+#pragma unroll
+    for (int k = 0; k < KH; ++k) {
+      const int row = tid + 256 * k;
+      const int c = row / 9, rem = row % 9, id = rem / 3, ih = rem % 3;
+      const int ci = ci0 + c, di = md0 + id, hi = mh0 + ih, wi = mw0 + 32;
+      rh[k] = 0.f;
+      if (row < ROWS && ci < a.Cin && di < a.Di && hi < a.Hi && wi < a.Wi)
+        rh[k] = a.x[((((long)n * a.Cin + ci) * a.Di + di) * a.Hi + hi) * a.Wi + wi];
+    }
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+      const int it = tid + 256 * k;
+      if (it < 27 * WQ) rw[k] = *(const float4*)(a.wt + ((long)(it / WQ) * a.CinPad + ci0) * CO + 4 * (it % WQ));
+    }
+  };
+  auto store_regs = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < KX; ++k) {
+      const int it = tid + 256 * k;
+      if (it < ROWS * 8) *(float4*)(in_lds + (it >> 3) * IWP + 4 + 4 * (it & 7)) = rx[k];
+    }
+#pragma unroll
+    for (int k = 0; k < KH; ++k) {
+      const int row = tid + 256 * k;
+      if (row < ROWS) in_lds[row * IWP + 36] = rh[k];
+    }
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+      const int it = tid + 256 * k;
+      if (it < 27 * WQ) *(float4*)(w_lds + (it / WQ) * CK * CO + 4 * (it % WQ)) = rw[k];
+    }
+  };
+
+  if constexpr (VEC) load_regs(0);
   for (int ci0 = 0; ci0 < a.CinPad; ci0 += CK) {
     __syncthreads();
-    if (VEC) {
-      for (int it = tid; it < ROWS * 8; it += 256) {
-        const int row = it >> 3, q = it & 7;
-        const int c = row / 9, rem = row % 9, id = rem / 3, ih = rem % 3;
-        const int ci = ci0 + c, di = md0 + id, hi = mh0 + ih, wi = mw0 + 4 * q;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ci < a.Cin && di < a.Di && hi < a.Hi && wi < a.Wi)
-          v = *(const float4*)(a.x + ((((long)n * a.Cin + ci) * a.Di + di) * a.Hi + hi) * a.Wi + wi);
-        *(float4*)(in_lds + row * IWP + 4 + 4 * q) = v;
-      }
-      for (int row = tid; row < ROWS; row += 256) {
-        const int c = row / 9, rem = row % 9, id = rem / 3, ih = rem % 3;
-        const int ci = ci0 + c, di = md0 + id, hi = mh0 + ih, wi = mw0 + 32;
-        float v = 0.f;
-        if (ci < a.Cin && di < a.Di && hi < a.Hi && wi < a.Wi)
-          v = a.x[((((long)n * a.Cin + ci) * a.Di + di) * a.Hi + hi) * a.Wi + wi];
-        in_lds[row * IWP + 36] = v;
-      }
+    if constexpr (VEC) {
+      store_regs();
     } else {
       for (int it = tid; it < ROWS * 33; it += 256) {
         const int row = it / 33, j = it % 33;
@@ -275,9 +309,6 @@ __global__ __launch_bounds__(256, 2) void deconv3_mfma_kernel(ConvArgs a) {
           v = a.x[((((long)n * a.Cin + ci) * a.Di + di) * a.Hi + hi) * a.Wi + wi];
         in_lds[row * IWP + 4 + j] = v;
       }
-    }
-    {
-      constexpr int WQ = CK * CO / 4;
       for (int it = tid; it < 27 * WQ; it += 256) {
         const int tap = it / WQ, q = it % WQ;
         *(float4*)(w_lds + tap * CK * CO + 4 * q) =
@@ -285,6 +316,9 @@ __global__ __launch_bounds__(256, 2) void deconv3_mfma_kernel(ConvArgs a) {
       }
     }
     __syncthreads();
+    if constexpr (VEC) {
+      if (ci0 + CK < a.CinPad) load_regs(ci0 + CK);
+    }
     const float* wb = w_lds + half * CO + l31;
     const float* inb = in_lds + boff;
 #pragma unroll

@@ -27,12 +27,15 @@ struct WgArgs {
   int vecx, vecy;
 };
 
-template <int S>
+// Tile = TD x TH x TW output voxels (256 for stride 1, 64 for stride 2); TW = 16 is chosen when it pads W less
+// (W = 240: 15 x 16 exactly instead of 8 x 32 = 256).
+template <int S, int TW>
 __global__ __launch_bounds__(256, 1) void wgrad3_kernel(WgArgs a) {
-  constexpr int TD = (S == 1) ? 2 : 1, TH = (S == 1) ? 4 : 2;
-  constexpr int NR = TD * TH, NV = NR * 32;
-  constexpr int ID = (TD - 1) * S + 3, IH = (TH - 1) * S + 3, IW = 31 * S + 3;
-  constexpr int IWP = (S == 1) ? 40 : 68;
+  static_assert(TW == 32 || (TW == 16 && S == 1), "tile width");
+  constexpr int TD = (S == 1) ? 2 : 1, TH = (S == 1) ? (TW == 32 ? 4 : 8) : 2;
+  constexpr int NR = TD * TH, NV = NR * TW;
+  constexpr int ID = (TD - 1) * S + 3, IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
+  constexpr int IWP = ((3 + IW + 3) / 4) * 4;
   constexpr int XP = ID * IH * IWP + 1;  // odd
   constexpr int YP = NV + 1;             // odd
   static_assert((XP & 1) && (YP & 1), "odd pitches");
@@ -63,8 +66,8 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(WgArgs a) {
   // loop of the current tile and written to LDS after it, so HBM/L2 latency hides under the matrix work
   // (one wave per SIMD here: 512 registers are available, the prefetch set is ~130).
   constexpr int ROWS = 32 * ID * IH;
-  constexpr int QPR = 8 * S, NH = (S == 1) ? 2 : 1;
-  constexpr int KX = (ROWS * QPR + 255) / 256, KH = (ROWS * NH + 255) / 256, KY = (32 * NR * 8 + 255) / 256;
+  constexpr int QPR = TW * S / 4, NH = (S == 1) ? 2 : 1, YQ = TW / 4;
+  constexpr int KX = (ROWS * QPR + 255) / 256, KH = (ROWS * NH + 255) / 256, KY = (32 * NR * YQ + 255) / 256;
   float4 rx[KX], ry[KY];
   float rh[KH];
   const bool pipelined = a.vecx && a.vecy;
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(WgArgs a) {
     const int th = t % a.nTH; t /= a.nTH;
     const int td = t % a.nTD;
     const int n = t / a.nTD;
-    const int d0 = td * TD, h0 = th * TH, w0 = tw * 32;
+    const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
     const int di0 = d0 * S - 1, hi0 = h0 * S - 1, wi0 = w0 * S - 1;
 #pragma unroll
     for (int k = 0; k < KX; ++k) {
@@ -101,10 +104,10 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(WgArgs a) {
 #pragma unroll
     for (int k = 0; k < KY; ++k) {
       const int it = tid + 256 * k;
-      const int q = it & 7, row = (it >> 3) % NR, c = it / (8 * NR);
+      const int q = it % YQ, row = (it / YQ) % NR, c = it / (YQ * NR);
       const int co = cy0 + c, d = d0 + row / TH, h = h0 + row % TH, w = w0 + 4 * q;
       ry[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (it < 32 * NR * 8 && co < a.Cy && d < a.Do && h < a.Ho && w < a.Wo)
+      if (it < 32 * NR * YQ && co < a.Cy && d < a.Do && h < a.Ho && w < a.Wo)
         ry[k] = *(const float4*)(a.dy + ((((long)n * a.Cy + co) * a.Do + d) * a.Ho + h) * a.Wo + w);
     }
   };
@@ -131,9 +134,9 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(WgArgs a) {
 #pragma unroll
     for (int k = 0; k < KY; ++k) {
       const int it = tid + 256 * k;
-      if (it < 32 * NR * 8) {
-        const int q = it & 7, row = (it >> 3) % NR, c = it / (8 * NR);
-        float* dst = ys + c * YP + row * 32 + 4 * q;
+      if (it < 32 * NR * YQ) {
+        const int q = it % YQ, row = (it / YQ) % NR, c = it / (YQ * NR);
+        float* dst = ys + c * YP + row * TW + 4 * q;
         dst[0] = ry[k].x; dst[1] = ry[k].y; dst[2] = ry[k].z; dst[3] = ry[k].w;
       }
     }
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(WgArgs a) {
       const int th = t % a.nTH; t /= a.nTH;
       const int td = t % a.nTD;
       const int n = t / a.nTD;
-      const int d0 = td * TD, h0 = th * TH, w0 = tw * 32;
+      const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
       const int di0 = d0 * S - 1, hi0 = h0 * S - 1, wi0 = w0 * S - 1;
       for (int it = tid; it < ROWS * IW; it += 256) {
         const int row = it / IW, j = it % IW;
@@ -163,12 +166,12 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(WgArgs a) {
         xs[c * XP + rem * IWP + 3 + j] = v;
       }
       for (int it = tid; it < 32 * NV; it += 256) {
-        const int wl = it & 31, row = (it >> 5) % NR, c = it / NV;
+        const int wl = it % TW, row = (it / TW) % NR, c = it / NV;
         const int co = cy0 + c, d = d0 + row / TH, h = h0 + row % TH, w = w0 + wl;
         float v = 0.f;
         if (co < a.Cy && d < a.Do && h < a.Ho && w < a.Wo)
           v = a.dy[((((long)n * a.Cy + co) * a.Do + d) * a.Ho + h) * a.Wo + w];
-        ys[c * YP + row * 32 + wl] = v;
+        ys[c * YP + row * TW + wl] = v;
       }
     }
     __syncthreads();
@@ -178,9 +181,9 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(WgArgs a) {
     for (int row = 0; row < NR; ++row) {
       const int dl = row / TH, hl = row % TH;
       const float* xr = xb + ((dl * S) * IH + hl * S) * IWP;
-      const float* yr = yb + row * 32;
+      const float* yr = yb + row * TW;
 #pragma unroll 4
-      for (int wp = 0; wp < 16; ++wp) {
+      for (int wp = 0; wp < TW / 2; ++wp) {
         const float av = yr[2 * wp];
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
@@ -292,6 +295,11 @@ static int wg_workers(int ntiles, int nCT) {
   return ntiles < w ? ntiles : w;
 }
 
+static int wg_tile_w(int ksize, int stride, int Wo) {
+  if (ksize != 3 || stride != 1) return 32;
+  return (cdiv(Wo, 16) * 16 < cdiv(Wo, 32) * 32) ? 16 : 32;
+}
+
 static void wg_geometry(int ksize, int stride, int N, int Do, int Ho, int Wo, int* nTD, int* nTH, int* nTW,
                         long* ntiles) {
   if (ksize == 1) {
@@ -300,8 +308,9 @@ static void wg_geometry(int ksize, int stride, int N, int Do, int Ho, int Wo, in
     *ntiles = (long)N * ((DHW + 255) / 256);
     return;
   }
-  const int TD = stride == 1 ? 2 : 1, TH = stride == 1 ? 4 : 2;
-  *nTD = cdiv(Do, TD); *nTH = cdiv(Ho, TH); *nTW = cdiv(Wo, 32);
+  const int TW = wg_tile_w(ksize, stride, Wo);
+  const int TD = stride == 1 ? 2 : 1, TH = stride == 1 ? (TW == 32 ? 4 : 8) : 2;
+  *nTD = cdiv(Do, TD); *nTH = cdiv(Ho, TH); *nTW = cdiv(Wo, TW);
   *ntiles = (long)N * *nTD * *nTH * *nTW;
 }
 
@@ -344,18 +353,24 @@ extern "C" int dca_conv3d_wgrad(const float* x, const float* dy, float* part, fl
   } else {
     a.vecx = (Wi % 4 == 0) && (((uintptr_t)x & 15) == 0);
     a.vecy = (Wo % 4 == 0) && (((uintptr_t)dy & 15) == 0);
-    if (stride == 1) {
-      const size_t lds = (size_t)(32 * (4 * 6 * 40 + 1) + 32 * 257) * 4;
-      hipError_t e = hipFuncSetAttribute((const void*)wgrad3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (stride == 1 && wg_tile_w(3, 1, Wo) == 16) {
+      const size_t lds = (size_t)(32 * (4 * 10 * 24 + 1) + 32 * 257) * 4;
+      hipError_t e = hipFuncSetAttribute((const void*)wgrad3_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds);
       if (e != hipSuccess) return (int)e;
-      hipLaunchKernelGGL(wgrad3_kernel<1>, grid, dim3(256), lds, stream, a);
+      hipLaunchKernelGGL((wgrad3_kernel<1, 16>), grid, dim3(256), lds, stream, a);
+    } else if (stride == 1) {
+      const size_t lds = (size_t)(32 * (4 * 6 * 40 + 1) + 32 * 257) * 4;
+      hipError_t e = hipFuncSetAttribute((const void*)wgrad3_kernel<1, 32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds);
+      if (e != hipSuccess) return (int)e;
+      hipLaunchKernelGGL((wgrad3_kernel<1, 32>), grid, dim3(256), lds, stream, a);
     } else {
       const size_t lds = (size_t)(32 * (3 * 5 * 68 + 1) + 32 * 65) * 4;
-      hipError_t e = hipFuncSetAttribute((const void*)wgrad3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+      hipError_t e = hipFuncSetAttribute((const void*)wgrad3_kernel<2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds);
       if (e != hipSuccess) return (int)e;
-      hipLaunchKernelGGL(wgrad3_kernel<2>, grid, dim3(256), lds, stream, a);
+      hipLaunchKernelGGL((wgrad3_kernel<2, 32>), grid, dim3(256), lds, stream, a);
     }
   }
   int st = dca_launch_status();

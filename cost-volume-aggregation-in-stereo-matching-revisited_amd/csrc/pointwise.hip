@@ -46,25 +46,26 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
 
 // stats[0..C) mean, [C..2C) invstd, [2C..3C) scale = gamma*invstd, [3C..4C) shift = beta - mean*scale.
 // training: batch statistics (+ running-stat update, momentum m, unbiased variance); otherwise running stats.
-__global__ void bn_finalize_kernel(const double* __restrict__ part, int nchunk, double count,
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const double* __restrict__ part, int nchunk, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
                                    float eps, int training, float* __restrict__ stats, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int c = blockIdx.x, lane = threadIdx.x;   // one wave per channel; lanes stride over the chunk partials
   float mean, var;
   if (training) {
     double s = 0.0, ss = 0.0;
-    for (int i = 0; i < nchunk; ++i) {
+    for (int i = lane; i < nchunk; i += 64) {
       s += part[((long)c * nchunk + i) * 2 + 0];
       ss += part[((long)c * nchunk + i) * 2 + 1];
     }
+    s = wave_sum_d(s);
+    ss = wave_sum_d(ss);
     const double m = s / count;
     double v = ss / count - m * m;
     if (v < 0.0) v = 0.0;
     mean = (float)m;
     var = (float)v;
-    if (running_mean) {
+    if (running_mean && lane == 0) {
       const double unb = count > 1.0 ? v * count / (count - 1.0) : v;
       running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
@@ -73,6 +74,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ part, int nchunk, 
     mean = running_mean[c];
     var = running_var[c];
   }
+  if (lane != 0) return;
   const float invstd = 1.0f / sqrtf(var + eps);
   const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
   stats[c] = mean;
@@ -162,15 +164,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 }
 
 // dgb[0..C) = dgamma, dgb[C..2C) = dbeta, dgb[2C..3C) = dbeta/count, dgb[3C..4C) = dgamma/count
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nchunk, double count,
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* __restrict__ part, int nchunk, double count,
                                        float* __restrict__ dgb, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int c = blockIdx.x, lane = threadIdx.x;
   double s0 = 0.0, s1 = 0.0;
-  for (int i = 0; i < nchunk; ++i) {
+  for (int i = lane; i < nchunk; i += 64) {
     s0 += part[((long)c * nchunk + i) * 2 + 0];
     s1 += part[((long)c * nchunk + i) * 2 + 1];
   }
+  s0 = wave_sum_d(s0);
+  s1 = wave_sum_d(s1);
+  if (lane != 0) return;
   dgb[c] = (float)s1;
   dgb[C + c] = (float)s0;
   dgb[2 * C + c] = (float)(s0 / count);
@@ -466,7 +470,7 @@ extern "C" int dca_bn_finalize(const double* part, int nchunk, double count, con
                                float* running_mean, float* running_var, float momentum, float eps, int training,
                                float* stats, int C, hipStream_t stream) {
   DCA_REQUIRE(stats && C > 0 && (training ? (part != nullptr && nchunk > 0) : (running_mean && running_var)));
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, part, nchunk, count, gamma, beta,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, stream, part, nchunk, count, gamma, beta,
                      running_mean, running_var, momentum, eps, training, stats, C);
   return dca_launch_status();
 }
@@ -492,7 +496,7 @@ extern "C" int dca_bn_backward(const float* dz, const float* y, const float* res
   const int vec = (S % 4 == 0) && ((al & 15) == 0);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, nchunk), dim3(256), 0, stream, dz, y, res_pre, stats, part, N, C, S,
                      nchunk, len, slope, vec);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, part, nchunk,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, stream, part, nchunk,
                      (double)N * (double)S, dgb, C);
   const long total = (long)N * C * S;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(vec ? total / 4 : total)), dim3(256), 0, stream, dz, y, res_pre,
