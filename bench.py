@@ -180,7 +180,7 @@ def main():
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
-    device = torch.device("cuda", local)
+    device = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(device)
 
     m = build_model(device)
