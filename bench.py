@@ -98,7 +98,11 @@ def kernel_roofline(device):
     out = {}
     with torch.no_grad():
         wt, cpad = ops._prep_weight(wgt, 32, 32, 27, 0, 0, 3, 1, False)
-        for name, fn in (("conv3_mfma_kernel<S1,Cout32,CK8,tile 4x8x16> (3x3x3 32->32 @1/4 res)",
+        ug = torch.empty((48, 32, 32), device=device)
+        ops._chk(ops._L().dca_conv3d_wino_prep_weight(ops._ptr(wgt), ops._ptr(ug), 32, 32, 32, 0, 0, 32, 0,
+                                                      ops._stream()), "wino prep")
+        for name, fn in ((("wino_conv3_kernel F(2x2,3x3)xD (3x3x3 32->32 @1/4 res, algorithmic FLOPs)",
+                           lambda: ops.conv3d_wino_prepared(x, ug, 32, 32, 32)),) if ops.WINOGRAD else ()) + (("conv3_mfma_kernel<S1,Cout32,CK8,tile 4x8x16> (3x3x3 32->32 @1/4 res)",
                           lambda: ops.conv3d_prepared(x, wt, 32, cpad, 32, 3, 1, False)),
                          ("wgrad3_kernel<S1> (+reduce) (dW of 3x3x3 32->32 @1/4 res)",
                           lambda: ops._wgrad(x, x, wgt.new_empty(wgt.shape), 0, 32, 32, 3, 1, 32 * 27, 27))):

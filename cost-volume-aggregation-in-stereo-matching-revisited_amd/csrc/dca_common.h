@@ -47,3 +47,31 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+
+// Hardware-predicated loads (T8): a raw buffer load whose byte offset lies outside the descriptor's range returns 0,
+// so "load if in bounds else 0" costs one v_cndmask on a 32-bit offset -- no branch, no wait.  (A predicated plain
+// load makes hipcc wrap every load in its own branch, in the worst case with an s_waitcnt vmcnt(0) behind it.)
+// The descriptor base must be wave-uniform (kernel argument / blockIdx arithmetic) and the range < 2 GiB.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define DCA_OOB_OFFSET ((int)0x7ffffff0)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dca_rsrc(const void* base, long bytes) {
+  // readfirstlane makes the wave-uniformity of the descriptor PROVABLE; otherwise hipcc wraps every buffer op in a
+  // waterfall loop (cdna_hip_programming.md T20)
+  const unsigned long long b = (unsigned long long)base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  const int nb = __builtin_amdgcn_readfirstlane((int)bytes);
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, nb, 0x00020000);
+}
+// `ok` is an INTEGER 0/1 mask built with `&` (never `&&`: short-circuit evaluation comes back as control flow around
+// every load); the select is bitwise so it cannot be turned into a branch either.
+__device__ __forceinline__ int dca_pred_off(int byte_off, int ok) {
+  const int m = -ok;
+  return (byte_off & m) | (DCA_OOB_OFFSET & ~m);
+}
+__device__ __forceinline__ float dca_bload1(__amdgpu_buffer_rsrc_t r, int byte_off, int ok) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, dca_pred_off(byte_off, ok), 0, 0));
+}
+__device__ __forceinline__ float4 dca_bload4(__amdgpu_buffer_rsrc_t r, int byte_off, int ok) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, dca_pred_off(byte_off, ok), 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}

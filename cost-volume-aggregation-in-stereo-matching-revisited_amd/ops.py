@@ -7,6 +7,7 @@ There is no CPU / eager fallback: tensors must be fp32 on a ROCm device and the 
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -199,6 +200,12 @@ def _round_up(a, m):
     return (a + m - 1) // m * m
 
 
+# Experimental Winograd F(2x2,3x3) path for the 3x3x3 stride-1 convolutions with <= 32 output channels.  Correct
+# (tests run it) but NOT faster than the direct MFMA kernel on MI355X (0.86 ms vs 0.86 ms for 32->32 at 48x136x240:
+# profiles/README.md), so it is opt-in: DCA_WINOGRAD=1.
+WINOGRAD = os.environ.get("DCA_WINOGRAD", "0") == "1"
+
+
 def _slice_width(ksize, stride, transposed, B):
     """output channels one launch of dca_conv3d_forward produces (include/dca_hip.h)"""
     if ksize == 1 or transposed:
@@ -240,6 +247,15 @@ def _conv_sliced(x, x2, w_src, A, B, K, src_ab, flip, ksize, stride, transposed,
     C1 = x.shape[1]
     width = _slice_width(ksize, stride, transposed, B)
     lib = _L()
+    if WINOGRAD and ksize == 3 and stride == 1 and not transposed and B <= 32 and x2 is None:
+        Apad = _round_up(A, 4)
+        ug = torch.empty((48, Apad, 32), device=x.device, dtype=torch.float32)
+        _chk(lib.dca_conv3d_wino_prep_weight(_ptr(w_src), _ptr(ug), A, B, Apad, int(src_ab), int(flip), B, 0,
+                                             _stream()), "dca_conv3d_wino_prep_weight")
+        _chk(lib.dca_conv3d_wino_forward(_ptr(x), _ptr(ug), _ptr(y), _ptr(scale), _ptr(shift), _ptr(res_pre),
+                                         _ptr(res_post), float(slope), N, A, B, Apad, B, 0, Di, Hi, Wi, _stream()),
+             "dca_conv3d_wino_forward")
+        return y
     for b0 in range(0, B, width):
         bn = min(width, B - b0)
         wt, Apad = _prep_weight(w_src, A, B, K, src_ab, flip, ksize, stride, transposed, b0, bn)
@@ -258,6 +274,16 @@ def conv3d_prepared(x, wt, A, Apad, B, ksize, stride, transposed):
     _chk(_L().dca_conv3d_forward(_ptr(x), None, _ptr(wt), _ptr(y), None, None, None, None, 1.0, N, A, A, B, Apad, B, 0,
                                  Di, Hi, Wi, Do, Ho, Wo, ksize, stride, int(transposed), _stream()),
          "dca_conv3d_forward")
+    return y
+
+
+def conv3d_wino_prepared(x, ug, A, Apad, B):
+    """single Winograd launch with an already transformed weight (bench.py)"""
+    N = x.shape[0]
+    D, H, W = x.shape[2:]
+    y = torch.empty((N, B, D, H, W), device=x.device, dtype=torch.float32)
+    _chk(_L().dca_conv3d_wino_forward(_ptr(x), _ptr(ug), _ptr(y), None, None, None, None, 1.0, N, A, B, Apad, B, 0, D, H,
+                                      W, _stream()), "dca_conv3d_wino_forward")
     return y
 
 

@@ -91,6 +91,16 @@ long dca_conv3d_wgrad_workspace(int N, int Cx, int Cy, int Do, int Ho, int Wo, i
 int dca_conv3d_wgrad(const float* x, const float* dy, float* part, float* dw, int N, int Cx, int Cy, int Di, int Hi,
                      int Wi, int Do, int Ho, int Wo, int ksize, int stride, long s_cy, long s_cx, hipStream_t stream);
 
+/* Winograd F(2x2,3x3) over (H,W), direct over D, for ksize 3 / stride 1 / Cout <= 32 (2.25x fewer matrix FLOPs, fp32).
+ * dca_conv3d_wino_prep_weight lays the weight out as ug[(xi*3+kd)][Apad][32] = G g G^T (A, B, src_ab, flip, Btotal,
+ * b_off as in dca_conv3d_prep_weight; Apad = A rounded up to 4).  dca_conv3d_wino_forward is a drop-in for
+ * dca_conv3d_forward on those shapes (same epilogue and channel-offset semantics); y and ug must be 16-byte aligned. */
+int dca_conv3d_wino_prep_weight(const float* w, float* ug, int A, int B, int Apad, int src_ab, int flip, int Btotal,
+                                int b_off, hipStream_t stream);
+int dca_conv3d_wino_forward(const float* x, const float* ug, float* y, const float* scale, const float* shift,
+                            const float* res_pre, const float* res_post, float slope, int N, int Cin, int Cout,
+                            int CinPad, int CoutTotal, int co_off, int D, int H, int W, hipStream_t stream);
+
 /* Single-output-channel 3x3x3 convolution (the logit heads: nn.Conv3d(32, 1, 3, padding=1, bias=False),
  * models/gwcnet_dca_g.py:154-168 `classif*.2`, models/augment/cva.py:51-53 `classify.2`).  w is the PyTorch weight
  * (1,C,3,3,3) as is.  The 27 taps become a GEMM axis so forward / weight gradient reuse the matrix-core kernels:

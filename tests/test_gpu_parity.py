@@ -163,6 +163,24 @@ def test_conv3d(case):
     close_l2(gw, gwr, 1e-5, "dw"); close(gw, gwr, 2e-5, "dw")
 
 
+@pytest.mark.parametrize("case", [(40, 32, (4, 6, 10), 2), (32, 32, (5, 10, 68), 1), (32, 27, (3, 9, 36), 1), (64, 32, (4, 8, 40), 1)])
+def test_conv3d_winograd_path(case, monkeypatch):
+    """the opt-in Winograd F(2x2,3x3)xD kernel (forward and, through autograd, stride-1 backward-data)"""
+    _, ops = _mods()
+    monkeypatch.setattr(ops, "WINOGRAD", True)
+    cin, cout, dims, N = case
+    x = seeded_tensor(f"wg.x{case}", (N, cin) + dims)
+    w = seeded_tensor(f"wg.w{case}", (cout, cin, 3, 3, 3)) * (1.0 / (cin * 27) ** 0.5)
+    xc, wc = cpu_leaf(x), cpu_leaf(w)
+    yr = F.conv3d(xc, wc, None, 1, 1)
+    gy = seeded_tensor(f"wg.g{case}", yr.shape)
+    gxr, gwr = torch.autograd.grad((yr * gy).sum(), [xc, wc])
+    xg, wg = gpu(x, True), gpu(w, True)
+    y = ops.conv3d(xg, wg, 1, False)
+    gx, gw = torch.autograd.grad((y * gy.to(DEV)).sum(), [xg, wg])
+    close(y, yr, 1e-5, "fwd"); close(gx, gxr, 1e-5, "dx"); close_l2(gw, gwr, 1e-5, "dw")
+
+
 def test_conv1x1_two_inputs():
     _, ops = _mods()
     dims, N = (4, 6, 12), 2
@@ -426,11 +444,14 @@ def test_golden_hot_path(golden, variant, training):
                   m.cva1.slc_net.cross_attention.query_project[0][0].weight, m.classif3[2].weight,
                   m.cva3.fuse[0][1].bias, m.classif1[0][0].weight]
         gr = grads_of([r[k] for k in keys], [f"hot.g{i}" for i in range(7)], [fL, fR] + params)
-        close_l2(gr[0][:, ::16], g["gfL"], 2e-3, "gfL"); close_l2(gr[1][:, ::16], g["gfR"], 2e-3, "gfR")
+        # End-to-end train-mode gradient gate 6e-3 rel-L2: on the CPU oracle itself a 1e-7 relative perturbation of
+        # the inputs changes these gradients by 0.8e-3 ... 2.5e-3 (isolated ReLU-mask flips under batch-stat BN,
+        # DESIGN.md section 2); every single kernel and module above is gated at 1e-5 ... 1e-3.
+        close_l2(gr[0][:, ::16], g["gfL"], 6e-3, "gfL"); close_l2(gr[1][:, ::16], g["gfR"], 6e-3, "gfR")
         gn = ["g_dres0_w", "g_dres1_bn2_w", "g_cva2_deconv_w", "g_cva1_q00_w", "g_cls3_w", "g_cva3_fuse_bnb",
               "g_cls1_w"]
         for got, name in zip(gr[2:], gn):
-            close_l2(thin(got), g[name], 1e-2 if name.endswith("bnb") else 2e-3, name)
+            close_l2(thin(got), g[name], 2e-2 if name.endswith("bnb") else 6e-3, name)
         close(m.dres0[0][1].running_mean, g["rm_dres0"], 1e-5)
     else:
         close(r["prob_volume2"].squeeze(1), g["prob_volume2"], 2e-5, "prob_volume2")
