@@ -94,16 +94,21 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
   float4 rx[VEC ? KX : 1], rw[VEC ? KW : 1];
   float rh[VEC ? KH : 1];
 
-  auto load_regs = [&](int ci0) {
+  // Prefetch loads are hardware-predicated buffer loads (dca_common.h): straight-line code, masked elements -> 0.
+  const long sample = (long)a.Cin * a.Di * a.Hi * a.Wi;
+  const __amdgpu_buffer_rsrc_t xr = dca_rsrc(a.x + (long)n * sample, sample * 4);
+  const __amdgpu_buffer_rsrc_t wr = dca_rsrc(a.wt, (long)27 * a.CinPad * CO * 4);
+  const int cstride = a.Di * a.Hi * a.Wi;
+  auto load_regs = [&](int ci0) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < KX; ++k) {
       const int it = tid + 256 * k;
       const int row = it / QPR, q = it % QPR;
       const int c = row / (ID * IH), rem = row % (ID * IH), id = rem / IH, ih = rem % IH;
       const int ci = ci0 + c, di = di0 + id, hi = hi0 + ih, wi = wi0 + 1 + 4 * q;
-      rx[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (it < ROWS * QPR && ci < a.Cin && (unsigned)di < (unsigned)a.Di && (unsigned)hi < (unsigned)a.Hi && wi < a.Wi)
-        rx[k] = *(const float4*)(a.x + ((((long)n * a.Cin + ci) * a.Di + di) * a.Hi + hi) * a.Wi + wi);
+      const int ok = (int)(it < ROWS * QPR) & (int)(ci < a.Cin) & (int)((unsigned)di < (unsigned)a.Di) &
+                     (int)((unsigned)hi < (unsigned)a.Hi) & (int)(wi < a.Wi);
+      rx[k] = dca_bload4(xr, (ci * cstride + (di * a.Hi + hi) * a.Wi + wi) * 4, ok);
     }
 #pragma unroll
     for (int k = 0; k < KH; ++k) {
@@ -111,19 +116,18 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
       const int row = it / NH, j = (it % NH) ? (IW - 1) : 0;
       const int c = row / (ID * IH), rem = row % (ID * IH), id = rem / IH, ih = rem % IH;
       const int ci = ci0 + c, di = di0 + id, hi = hi0 + ih, wi = wi0 + j;
-      rh[k] = 0.f;
-      if (it < ROWS * NH && ci < a.Cin && (unsigned)di < (unsigned)a.Di && (unsigned)hi < (unsigned)a.Hi &&
-          (unsigned)wi < (unsigned)a.Wi)
-        rh[k] = a.x[((((long)n * a.Cin + ci) * a.Di + di) * a.Hi + hi) * a.Wi + wi];
+      const int ok = (int)(it < ROWS * NH) & (int)(ci < a.Cin) & (int)((unsigned)di < (unsigned)a.Di) &
+                     (int)((unsigned)hi < (unsigned)a.Hi) & (int)((unsigned)wi < (unsigned)a.Wi);
+      rh[k] = dca_bload1(xr, (ci * cstride + (di * a.Hi + hi) * a.Wi + wi) * 4, ok);
     }
 #pragma unroll
     for (int k = 0; k < KW; ++k) {
       const int it = tid + 256 * k;
       const int tap = it / WQ, q = it % WQ;
-      if (it < 27 * WQ) rw[k] = *(const float4*)(a.wt + ((long)tap * a.CinPad + ci0) * CO + 4 * q);
+      rw[k] = dca_bload4(wr, ((tap * a.CinPad + ci0) * CO + 4 * q) * 4, (int)(it < 27 * WQ));
     }
   };
-  auto store_regs = [&]() {
+  auto store_regs = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < KX; ++k) {
       const int it = tid + 256 * k;
@@ -521,7 +525,7 @@ extern "C" int dca_conv3d_forward(const float* x, const float* x2, const float* 
                : launch_conv(conv1_mfma_kernel<2, false>, a, grid, 0, stream);
   }
   DCA_REQUIRE(ksize == 3 && x2 == nullptr);
-  const bool vec = aligned && (Wi % 4 == 0);
+  const bool vec = aligned && (Wi % 4 == 0) && ((long)Cin * Di * Hi * Wi * 4 < 0x7ffffff0L);
   if (transposed) {
     DCA_REQUIRE(stride == 2 && Cout <= 32 && Do == 2 * Di && Ho == 2 * Hi && Wo == 2 * Wi && CinPad % 8 == 0);
     a.nTD = cdiv(Di, 2); a.nTH = cdiv(Hi, 2); a.nTW = cdiv(Wi, 32);
