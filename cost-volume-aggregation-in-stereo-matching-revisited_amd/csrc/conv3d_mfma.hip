@@ -254,6 +254,10 @@ __global__ __launch_bounds__(256, 2) void deconv3_mfma_kernel(ConvArgs a) {
   constexpr int KX = (ROWS * 8 + 255) / 256, KH = (ROWS + 255) / 256, KW = (27 * WQ + 255) / 256;
   float4 rx[VEC ? KX : 1], rw[VEC ? KW : 1];
   float rh[VEC ? KH : 1];
+  const long sample = (long)a.Cin * a.Di * a.Hi * a.Wi;
+  const __amdgpu_buffer_rsrc_t xr = dca_rsrc(a.x + (long)n * sample, sample * 4);
+  const __amdgpu_buffer_rsrc_t wr = dca_rsrc(a.wt, (long)27 * a.CinPad * CO * 4);
+  const int cstride = a.Di * a.Hi * a.Wi;
   auto load_regs = [&](int ci0) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < KX; ++k) {
@@ -261,23 +265,21 @@ __global__ __launch_bounds__(256, 2) void deconv3_mfma_kernel(ConvArgs a) {
       const int row = it >> 3, q = it & 7;
       const int c = row / 9, rem = row % 9, id = rem / 3, ih = rem % 3;
       const int ci = ci0 + c, di = md0 + id, hi = mh0 + ih, wi = mw0 + 4 * q;
-      rx[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (it < ROWS * 8 && ci < a.Cin && di < a.Di && hi < a.Hi && wi < a.Wi)
-        rx[k] = *(const float4*)(a.x + ((((long)n * a.Cin + ci) * a.Di + di) * a.Hi + hi) * a.Wi + wi);
+      const int ok = (int)(it < ROWS * 8) & (int)(ci < a.Cin) & (int)(di < a.Di) & (int)(hi < a.Hi) & (int)(wi < a.Wi);
+      rx[k] = dca_bload4(xr, (ci * cstride + (di * a.Hi + hi) * a.Wi + wi) * 4, ok);
     }
 #pragma unroll
     for (int k = 0; k < KH; ++k) {
       const int row = tid + 256 * k;
       const int c = row / 9, rem = row % 9, id = rem / 3, ih = rem % 3;
       const int ci = ci0 + c, di = md0 + id, hi = mh0 + ih, wi = mw0 + 32;
-      rh[k] = 0.f;
-      if (row < ROWS && ci < a.Cin && di < a.Di && hi < a.Hi && wi < a.Wi)
-        rh[k] = a.x[((((long)n * a.Cin + ci) * a.Di + di) * a.Hi + hi) * a.Wi + wi];
+      const int ok = (int)(row < ROWS) & (int)(ci < a.Cin) & (int)(di < a.Di) & (int)(hi < a.Hi) & (int)(wi < a.Wi);
+      rh[k] = dca_bload1(xr, (ci * cstride + (di * a.Hi + hi) * a.Wi + wi) * 4, ok);
     }
 #pragma unroll
     for (int k = 0; k < KW; ++k) {
       const int it = tid + 256 * k;
-      if (it < 27 * WQ) rw[k] = *(const float4*)(a.wt + ((long)(it / WQ) * a.CinPad + ci0) * CO + 4 * (it % WQ));
+      rw[k] = dca_bload4(wr, (((it / WQ) * a.CinPad + ci0) * CO + 4 * (it % WQ)) * 4, (int)(it < 27 * WQ));
     }
   };
   auto store_regs = [&]() __attribute__((always_inline)) {

@@ -24,7 +24,7 @@ struct WgArgs {
   float* part;
   int N, Cx, Cy, Di, Hi, Wi, Do, Ho, Wo;
   int nTD, nTH, nTW, ntiles, nCxT;
-  int vecx, vecy;
+  int vecx, vecy, small_offsets;
 };
 
 // Tile = TD x TH x TW output voxels (256 for stride 1, 64 for stride 2); TW = 16 is chosen when it pads W less
@@ -70,9 +70,12 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(WgArgs a) {
   constexpr int KX = (ROWS * QPR + 255) / 256, KH = (ROWS * NH + 255) / 256, KY = (32 * NR * YQ + 255) / 256;
   float4 rx[KX], ry[KY];
   float rh[KH];
-  const bool pipelined = a.vecx && a.vecy;
+  const bool pipelined = a.vecx && a.vecy && a.small_offsets;
 
-  auto load_regs = [&](int tile) {
+  // prefetch loads are hardware-predicated buffer loads (dca_common.h): straight-line code, masked elements -> 0
+  const __amdgpu_buffer_rsrc_t xr = dca_rsrc(a.x, (long)a.N * a.Cx * a.Di * a.Hi * a.Wi * 4);
+  const __amdgpu_buffer_rsrc_t yr_ = dca_rsrc(a.dy, (long)a.N * a.Cy * a.Do * a.Ho * a.Wo * 4);
+  auto load_regs = [&](int tile) __attribute__((always_inline)) {
     int t = tile;
     const int tw = t % a.nTW; t /= a.nTW;
     const int th = t % a.nTH; t /= a.nTH;
@@ -86,9 +89,9 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(WgArgs a) {
       const int row = it / QPR, q = it % QPR;
       const int c = row / (ID * IH), rem = row % (ID * IH), id = rem / IH, ih = rem % IH;
       const int ci = cx0 + c, di = di0 + id, hi = hi0 + ih, wi = wi0 + 1 + 4 * q;
-      rx[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (it < ROWS * QPR && ci < a.Cx && (unsigned)di < (unsigned)a.Di && (unsigned)hi < (unsigned)a.Hi && wi < a.Wi)
-        rx[k] = *(const float4*)(a.x + ((((long)n * a.Cx + ci) * a.Di + di) * a.Hi + hi) * a.Wi + wi);
+      const int ok = (int)(it < ROWS * QPR) & (int)(ci < a.Cx) & (int)((unsigned)di < (unsigned)a.Di) &
+                     (int)((unsigned)hi < (unsigned)a.Hi) & (int)(wi < a.Wi);
+      rx[k] = dca_bload4(xr, ((((n * a.Cx + ci) * a.Di + di) * a.Hi + hi) * a.Wi + wi) * 4, ok);
     }
 #pragma unroll
     for (int k = 0; k < KH; ++k) {
@@ -96,22 +99,20 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(WgArgs a) {
       const int row = it / NH, j = (it % NH) ? (IW - 1) : 0;
       const int c = row / (ID * IH), rem = row % (ID * IH), id = rem / IH, ih = rem % IH;
       const int ci = cx0 + c, di = di0 + id, hi = hi0 + ih, wi = wi0 + j;
-      rh[k] = 0.f;
-      if (it < ROWS * NH && ci < a.Cx && (unsigned)di < (unsigned)a.Di && (unsigned)hi < (unsigned)a.Hi &&
-          (unsigned)wi < (unsigned)a.Wi)
-        rh[k] = a.x[((((long)n * a.Cx + ci) * a.Di + di) * a.Hi + hi) * a.Wi + wi];
+      const int ok = (int)(it < ROWS * NH) & (int)(ci < a.Cx) & (int)((unsigned)di < (unsigned)a.Di) &
+                     (int)((unsigned)hi < (unsigned)a.Hi) & (int)((unsigned)wi < (unsigned)a.Wi);
+      rh[k] = dca_bload1(xr, ((((n * a.Cx + ci) * a.Di + di) * a.Hi + hi) * a.Wi + wi) * 4, ok);
     }
 #pragma unroll
     for (int k = 0; k < KY; ++k) {
       const int it = tid + 256 * k;
       const int q = it % YQ, row = (it / YQ) % NR, c = it / (YQ * NR);
       const int co = cy0 + c, d = d0 + row / TH, h = h0 + row % TH, w = w0 + 4 * q;
-      ry[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (it < 32 * NR * YQ && co < a.Cy && d < a.Do && h < a.Ho && w < a.Wo)
-        ry[k] = *(const float4*)(a.dy + ((((long)n * a.Cy + co) * a.Do + d) * a.Ho + h) * a.Wo + w);
+      const int ok = (int)(it < 32 * NR * YQ) & (int)(co < a.Cy) & (int)(d < a.Do) & (int)(h < a.Ho) & (int)(w < a.Wo);
+      ry[k] = dca_bload4(yr_, ((((n * a.Cy + co) * a.Do + d) * a.Ho + h) * a.Wo + w) * 4, ok);
     }
   };
-  auto store_regs = [&]() {
+  auto store_regs = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < KX; ++k) {
       const int it = tid + 256 * k;
@@ -338,6 +339,7 @@ extern "C" int dca_conv3d_wgrad(const float* x, const float* dy, float* part, fl
   wg_geometry(ksize, stride, N, Do, Ho, Wo, &a.nTD, &a.nTH, &a.nTW, &ntiles);
   DCA_REQUIRE(ntiles < (1L << 31));
   a.ntiles = (int)ntiles;
+  a.small_offsets = ((long)N * Cx * Di * Hi * Wi * 4 < 0x7ffffff0L) && ((long)N * Cy * Do * Ho * Wo * 4 < 0x7ffffff0L);
   a.nCxT = cdiv(Cx, 32);
   const int nCT = a.nCxT * cdiv(Cy, 32);
   const int K = ksize == 1 ? 1 : 27;
