@@ -116,32 +116,35 @@ __global__ __launch_bounds__(256) void c1_bwd_data_kernel(C1Args a) {
 //   forward : T[t][v'] = sum_ci w[ci][t] x[ci][v']  (conv1_mfma_kernel, 32 -> 27)      y[v] = sum_t T[t][v + t - 1]
 //   wgrad   : G[t][v'] = dy[v' - (t - 1)]                                              dW[ci][t] = sum_v' x[ci][v'] G[t][v']
 // (t - 1) is the 3D tap offset (kd-1, kh-1, kw-1); out-of-volume positions contribute zero.
-__global__ void c1_gather_kernel(const float* __restrict__ T, float* __restrict__ y, int N, int D, int H, int W) {
-  const long DHW = (long)D * H * W, total = (long)N * DHW;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+// grid (voxel tiles, N): the sample base is wave-uniform, so each of the 27 shifted taps is one hardware-predicated
+// buffer load (one descriptor per kd slab of 9 tap planes) -- 27 independent loads in flight, no branches.
+__global__ __launch_bounds__(256) void c1_gather_kernel(const float* __restrict__ T, float* __restrict__ y, int D, int H,
+                                                        int W) {
+  const long DHW = (long)D * H * W;
+  const long n = blockIdx.y;
+  const float* p = T + n * 27 * DHW;
+  const long end = min(DHW, ((long)blockIdx.x + 1) * 1024);
+  for (long idx = (long)blockIdx.x * 1024 + threadIdx.x; idx < end; idx += 256) {
     const int w = idx % W;
-    long t = idx / W;
-    const int h = t % H; t /= H;
-    const int d = t % D;
-    const long n = t / D;
-    const float* p = T + n * 27 * DHW;
+    const int t = (int)(idx / W);
+    const int h = t % H, d = t / H;
     float s = 0.f;
 #pragma unroll
     for (int kd = 0; kd < 3; ++kd) {
       const int dd = d + kd - 1;
-      if ((unsigned)dd >= (unsigned)D) continue;
+      const __amdgpu_buffer_rsrc_t r = dca_rsrc(p + kd * 9 * DHW, 9 * DHW * 4);  // one descriptor per kd slab
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) {
         const int hh = h + kh - 1;
-        if ((unsigned)hh >= (unsigned)H) continue;
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
           const int ww = w + kw - 1;
-          if ((unsigned)ww < (unsigned)W) s += p[((kd * 3 + kh) * 3 + kw) * DHW + ((long)dd * H + hh) * W + ww];
+          const int ok = (int)((unsigned)dd < (unsigned)D) & (int)((unsigned)hh < (unsigned)H) & (int)((unsigned)ww < (unsigned)W);
+          s += dca_bload1(r, ((kh * 3 + kw) * (int)DHW + (dd * H + hh) * W + ww) * 4, ok);
         }
       }
     }
-    y[idx] = s;
+    y[n * DHW + idx] = s;
   }
 }
 
@@ -185,9 +188,8 @@ extern "C" int dca_conv3d_c1_bwd_data(const float* dy, const float* w, float* dx
 
 extern "C" int dca_conv3d_c1_gather(const float* T, float* y, int N, int D, int H, int W, hipStream_t stream) {
   DCA_REQUIRE(T && y && N > 0 && D > 0 && H > 0 && W > 0);
-  const long total = (long)N * D * H * W;
-  const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(c1_gather_kernel, dim3(grid), dim3(256), 0, stream, T, y, N, D, H, W);
+  DCA_REQUIRE(9L * D * H * W * 4 < 0x7ffffff0L && N <= 65535);  // 32-bit byte offsets inside one kd slab
+  hipLaunchKernelGGL(c1_gather_kernel, dim3(cdiv((long)D * H * W, 1024), N), dim3(256), 0, stream, T, y, D, H, W);
   return dca_launch_status();
 }
 

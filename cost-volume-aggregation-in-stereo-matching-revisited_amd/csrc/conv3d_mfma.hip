@@ -197,21 +197,51 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
     }
   }
 
+  // Epilogue.  The optional affine / residual operands are loaded in batches behind uniform null checks (a per-
+  // element `if (ptr) v += ptr[idx]` compiles to one dependent load + s_waitcnt vmcnt(0) per output element).
   const int w = w0 + wl;
+  const bool has_aff = a.scale != nullptr, has_pre = a.res_pre != nullptr, has_post = a.res_post != nullptr;
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int r0 = (wv * NT + t) * RPT + hsel, d = d0 + r0 / TH, h = h0 + r0 % TH;
-    if (d >= a.Do || h >= a.Ho || w >= a.Wo) continue;
+  for (int ct = 0; ct < CT; ++ct) {
+    float sc[16], sh[16];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
+    for (int r = 0; r < 16; ++r) {
+      const int co = min(ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, a.Cout - 1);
+      sc[r] = has_aff ? a.scale[a.co_off + co] : 1.f;
+      sh[r] = has_aff ? a.shift[a.co_off + co] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int r0 = (wv * NT + t) * RPT + hsel, d = d0 + r0 / TH, h = h0 + r0 % TH;
+      const bool ok = d < a.Do && h < a.Ho && w < a.Wo;
+      const long plane = (long)a.Do * a.Ho * a.Wo;
+      const long base = (((long)n * a.CoutTotal + a.co_off) * a.Do + (ok ? d : 0)) * a.Ho * (long)a.Wo +
+                        (long)(ok ? h : 0) * a.Wo + (ok ? w : 0);
+      float rp[16], rq[16];
+      if (has_pre) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = min(ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, a.Cout - 1);
+          rp[r] = a.res_pre[base + co * plane];
+        }
+      }
+      if (has_post) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = min(ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, a.Cout - 1);
+          rq[r] = a.res_post[base + co * plane];
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (co < a.Cout) {
-          const long idx = ((((long)n * a.CoutTotal + a.co_off + co) * a.Do + d) * a.Ho + h) * a.Wo + w;
-          a.y[idx] = epilogue(a, acc[t][ct][r], co, idx);
-        }
+        float v = acc[t][ct][r] * sc[r] + sh[r];
+        if (has_pre) v += rp[r];
+        v = act_apply(v, a.slope);
+        if (has_post) v += rq[r];
+        if (ok && co < a.Cout) a.y[base + co * plane] = v;
       }
+    }
   }
 }
 
@@ -346,30 +376,50 @@ __global__ __launch_bounds__(256, 2) void deconv3_mfma_kernel(ConvArgs a) {
   }
 
   const int md = md0 + mdl, mh = mh0 + mhl, mw = mw0 + l31;
-  if (md < a.Di && mh < a.Hi && mw < a.Wi) {
+  const bool ok = md < a.Di && mh < a.Hi && mw < a.Wi;
+  const bool has_aff = a.scale != nullptr, has_pre = a.res_pre != nullptr, has_post = a.res_post != nullptr;
+  float sc[16], sh[16];
 #pragma unroll
-    for (int pd = 0; pd < 2; ++pd)
+  for (int r = 0; r < 16; ++r) {
+    const int co = min((r & 3) + 8 * (r >> 2) + 4 * half, a.Cout - 1);
+    sc[r] = has_aff ? a.scale[a.co_off + co] : 1.f;
+    sh[r] = has_aff ? a.shift[a.co_off + co] : 0.f;
+  }
+  const long plane = (long)a.Do * a.Ho * a.Wo;
 #pragma unroll
-      for (int ph = 0; ph < 2; ++ph) {
-        const int d = 2 * md + pd, h = 2 * mh + ph;
+  for (int pd = 0; pd < 2; ++pd)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (co < a.Cout) {
-            const long idx = ((((long)n * a.CoutTotal + a.co_off + co) * a.Do + d) * a.Ho + h) * a.Wo + 2 * mw;
-            float2 o = make_float2(acc[(pd * 2 + ph) * 2 + 0][r], acc[(pd * 2 + ph) * 2 + 1][r]);
-            if (a.scale) {
-              const float sc = a.scale[a.co_off + co], sh = a.shift[a.co_off + co];
-              o.x = o.x * sc + sh; o.y = o.y * sc + sh;
-            }
-            if (a.res_pre) { const float2 rp = *(const float2*)(a.res_pre + idx); o.x += rp.x; o.y += rp.y; }
-            o.x = act_apply(o.x, a.slope); o.y = act_apply(o.y, a.slope);
-            if (a.res_post) { const float2 rq = *(const float2*)(a.res_post + idx); o.x += rq.x; o.y += rq.y; }
-            *(float2*)(a.y + idx) = o;
+    for (int ph = 0; ph < 2; ++ph) {
+      const int d = ok ? 2 * md + pd : 0, h = ok ? 2 * mh + ph : 0, w = ok ? 2 * mw : 0;
+      const long base = (((long)n * a.CoutTotal + a.co_off) * a.Do + d) * a.Ho * (long)a.Wo + (long)h * a.Wo + w;
+#pragma unroll
+      for (int rc = 0; rc < 16; rc += 8) {
+        float2 rp[8], rq[8];
+        if (has_pre) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int r = rc + q;
+            rp[q] = *(const float2*)(a.res_pre + base + min((r & 3) + 8 * (r >> 2) + 4 * half, a.Cout - 1) * plane);
           }
         }
+        if (has_post) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int r = rc + q;
+            rq[q] = *(const float2*)(a.res_post + base + min((r & 3) + 8 * (r >> 2) + 4 * half, a.Cout - 1) * plane);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int r = rc + q, co = (r & 3) + 8 * (r >> 2) + 4 * half;
+          float2 o = make_float2(acc[(pd * 2 + ph) * 2 + 0][r] * sc[r] + sh[r], acc[(pd * 2 + ph) * 2 + 1][r] * sc[r] + sh[r]);
+          if (has_pre) { o.x += rp[q].x; o.y += rp[q].y; }
+          o.x = act_apply(o.x, a.slope); o.y = act_apply(o.y, a.slope);
+          if (has_post) { o.x += rq[q].x; o.y += rq[q].y; }
+          if (ok && co < a.Cout) *(float2*)(a.y + base + co * plane) = o;
+        }
       }
-  }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -387,6 +437,16 @@ __global__ __launch_bounds__(256) void conv1_mfma_kernel(ConvArgs a) {
 #pragma unroll
   for (int kk = 0; kk < NG * 16; ++kk) aw[kk] = a.wt[(2 * kk + half) * 32 + l31];
 
+  const bool has_aff = a.scale != nullptr, has_pre = a.res_pre != nullptr, has_post = a.res_post != nullptr;
+  float sc[16], sh[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = min((r & 3) + 8 * (r >> 2) + 4 * half, a.Cout - 1);
+    sc[r] = has_aff ? a.scale[a.co_off + co] : 1.f;
+    sh[r] = has_aff ? a.shift[a.co_off + co] : 0.f;
+  }
+  // hardware-predicated loads of the activations (dca_common.h): 32-bit offsets inside one (sample, tensor)
+  const bool boff_ok = a.xs_n * 4 < 0x7ffffff0L && a.x2s_n * 4 < 0x7ffffff0L;
   for (long g = (long)blockIdx.x * 4 + wv; g < total; g += (long)gridDim.x * 4) {
     const int n = (int)(g / ngroups);
     const long v = (g % ngroups) * 128 + 4 * l31;
@@ -397,14 +457,17 @@ __global__ __launch_bounds__(256) void conv1_mfma_kernel(ConvArgs a) {
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 #pragma unroll
     for (int grp = 0; grp < NG; ++grp) {
-      const float* xp = (grp == 0 ? a.x + n * a.xs_n : a.x2 + n * a.x2s_n) + v;
+      const float* xbase = (grp == 0 ? a.x + n * a.xs_n : a.x2 + n * a.x2s_n);
       float4 b[16];
+      if (VEC && boff_ok) {
+        const __amdgpu_buffer_rsrc_t xr = dca_rsrc(xbase, (grp == 0 ? a.xs_n : a.x2s_n) * 4);
 #pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
-        const float* p = xp + (long)(2 * kk + half) * DHW;
-        if (VEC) {
-          b[kk] = (v < DHW) ? *(const float4*)p : make_float4(0.f, 0.f, 0.f, 0.f);
-        } else {
+        for (int kk = 0; kk < 16; ++kk)
+          b[kk] = dca_bload4(xr, (int)(((long)(2 * kk + half) * DHW + v) * 4), (int)(v < DHW));
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+          const float* p = xbase + v + (long)(2 * kk + half) * DHW;
           b[kk].x = (v + 0 < DHW) ? p[0] : 0.f;
           b[kk].y = (v + 1 < DHW) ? p[1] : 0.f;
           b[kk].z = (v + 2 < DHW) ? p[2] : 0.f;
@@ -420,25 +483,47 @@ __global__ __launch_bounds__(256) void conv1_mfma_kernel(ConvArgs a) {
         acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b[kk].w, acc[3], 0, 0, 0);
       }
     }
+    const bool inr = v < DHW;
+    const long base = ((long)n * a.CoutTotal + a.co_off) * DHW + (inr ? v : 0);
+    if (VEC) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (co >= a.Cout) continue;
-      const long idx = ((long)n * a.CoutTotal + a.co_off + co) * DHW + v;
-      if (VEC) {
-        if (v < DHW) {
-          float4 o;
-          o.x = epilogue(a, acc[0][r], co, idx + 0);
-          o.y = epilogue(a, acc[1][r], co, idx + 1);
-          o.z = epilogue(a, acc[2][r], co, idx + 2);
-          o.w = epilogue(a, acc[3][r], co, idx + 3);
-          *(float4*)(a.y + idx) = o;
+      for (int rc = 0; rc < 16; rc += 4) {  // 4 rows at a time: enough loads in flight, no spills
+        float4 rp[4], rq[4];
+        if (has_pre) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int r = rc + q;
+            rp[q] = *(const float4*)(a.res_pre + base + min((r & 3) + 8 * (r >> 2) + 4 * half, a.Cout - 1) * DHW);
+          }
         }
-      } else {
-        if (v + 0 < DHW) a.y[idx + 0] = epilogue(a, acc[0][r], co, idx + 0);
-        if (v + 1 < DHW) a.y[idx + 1] = epilogue(a, acc[1][r], co, idx + 1);
-        if (v + 2 < DHW) a.y[idx + 2] = epilogue(a, acc[2][r], co, idx + 2);
-        if (v + 3 < DHW) a.y[idx + 3] = epilogue(a, acc[3][r], co, idx + 3);
+        if (has_post) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int r = rc + q;
+            rq[q] = *(const float4*)(a.res_post + base + min((r & 3) + 8 * (r >> 2) + 4 * half, a.Cout - 1) * DHW);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = rc + q, co = (r & 3) + 8 * (r >> 2) + 4 * half;
+          float o[4] = {acc[0][r] * sc[r] + sh[r], acc[1][r] * sc[r] + sh[r], acc[2][r] * sc[r] + sh[r],
+                        acc[3][r] * sc[r] + sh[r]};
+          if (has_pre) { o[0] += rp[q].x; o[1] += rp[q].y; o[2] += rp[q].z; o[3] += rp[q].w; }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = act_apply(o[j], a.slope);
+          if (has_post) { o[0] += rq[q].x; o[1] += rq[q].y; o[2] += rq[q].z; o[3] += rq[q].w; }
+          if (inr && co < a.Cout) *(float4*)(a.y + base + co * DHW) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (co >= a.Cout) continue;
+        const long idx = ((long)n * a.CoutTotal + a.co_off + co) * DHW + v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (v + j < DHW) a.y[idx + j] = epilogue(a, acc[j][r], co, idx + j);
       }
     }
   }

@@ -223,58 +223,62 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* _
 }
 
 // ------------------------------------------------------------------------------------ AvgPool3d(3, 2, 1)
-__global__ void avgpool3d_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long NC, int Di, int Hi,
-                                     int Wi, int Do, int Ho, int Wo) {
-  const long total = NC * Do * Ho * Wo;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int ow = idx % Wo;
-    long t = idx / Wo;
-    const int oh = t % Ho; t /= Ho;
-    const int od = t % Do;
-    const long nc = t / Do;
-    const float* p = x + nc * Di * Hi * Wi;
+// One block row = one (channel, output depth) plane, so the channel base is wave-uniform and every tap is a
+// hardware-predicated buffer load (dca_common.h): 27 independent loads in flight per output, no per-tap branches.
+__global__ __launch_bounds__(256) void avgpool3d_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int Di,
+                                                            int Hi, int Wi, int Do, int Ho, int Wo) {
+  const long row = blockIdx.x;
+  const int od = (int)(row % Do);
+  const long nc = row / Do;
+  const long plane = (long)Di * Hi * Wi;
+  const __amdgpu_buffer_rsrc_t xr = dca_rsrc(x + nc * plane, plane * 4);
+  const int HW = Ho * Wo, end = min(HW, ((int)blockIdx.y + 1) * 1024);
+  for (int i = blockIdx.y * 1024 + threadIdx.x; i < end; i += 256) {
+    const int oh = i / Wo, ow = i - oh * Wo;
     float s = 0.f;
 #pragma unroll
     for (int kd = 0; kd < 3; ++kd) {
       const int d = 2 * od - 1 + kd;
-      if ((unsigned)d >= (unsigned)Di) continue;
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) {
         const int h = 2 * oh - 1 + kh;
-        if ((unsigned)h >= (unsigned)Hi) continue;
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
           const int w = 2 * ow - 1 + kw;
-          if ((unsigned)w < (unsigned)Wi) s += p[((long)d * Hi + h) * Wi + w];
+          const int ok = (int)((unsigned)d < (unsigned)Di) & (int)((unsigned)h < (unsigned)Hi) & (int)((unsigned)w < (unsigned)Wi);
+          s += dca_bload1(xr, ((d * Hi + h) * Wi + w) * 4, ok);
         }
       }
     }
-    y[idx] = s * (1.0f / 27.0f);  // count_include_pad=True: always /27
+    y[row * HW + i] = s * (1.0f / 27.0f);  // count_include_pad=True: always /27
   }
 }
 
-__global__ void avgpool3d_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, long NC, int Di, int Hi,
-                                     int Wi, int Do, int Ho, int Wo) {
-  const long total = NC * Di * Hi * Wi;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int w = idx % Wi;
-    long t = idx / Wi;
-    const int h = t % Hi; t /= Hi;
-    const int d = t % Di;
-    const long nc = t / Di;
-    const float* p = gy + nc * Do * Ho * Wo;
-    // outputs o with 2o-1+k = i, k in {0,1,2}: o in [ceil((i-1)/2), floor((i+1)/2)]
-    const int d0 = d >> 1, d1 = (d + 1) >> 1, h0 = h >> 1, h1 = (h + 1) >> 1, w0 = w >> 1, w1 = (w + 1) >> 1;
+__global__ __launch_bounds__(256) void avgpool3d_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int Di,
+                                                            int Hi, int Wi, int Do, int Ho, int Wo) {
+  const long row = blockIdx.x;
+  const int d = (int)(row % Di);
+  const long nc = row / Di;
+  const long plane = (long)Do * Ho * Wo;
+  const __amdgpu_buffer_rsrc_t gr = dca_rsrc(gy + nc * plane, plane * 4);
+  const int HW = Hi * Wi, end = min(HW, ((int)blockIdx.y + 1) * 1024);
+  // outputs o with 2o-1+k = i, k in {0,1,2}: o in [ceil((i-1)/2), floor((i+1)/2)] = {i>>1, (i+1)>>1}
+  const int d0 = d >> 1, dn = d & 1;
+  for (int i = blockIdx.y * 1024 + threadIdx.x; i < end; i += 256) {
+    const int h = i / Wi, w = i - h * Wi;
+    const int h0 = h >> 1, hn = h & 1, w0 = w >> 1, wn = w & 1;
     float s = 0.f;
-    for (int od = d0; od <= d1; ++od) {
-      if (od >= Do) continue;
-      for (int oh = h0; oh <= h1; ++oh) {
-        if (oh >= Ho) continue;
-        for (int ow = w0; ow <= w1; ++ow)
-          if (ow < Wo) s += p[((long)od * Ho + oh) * Wo + ow];
-      }
-    }
-    gx[idx] = s * (1.0f / 27.0f);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int od = d0 + a, oh = h0 + b, ow = w0 + c;
+          const int ok = (a <= dn) & (b <= hn) & (c <= wn) & (int)(od < Do) & (int)(oh < Ho) & (int)(ow < Wo);
+          s += dca_bload1(gr, ((od * Ho + oh) * Wo + ow) * 4, ok);
+        }
+    gx[row * HW + i] = s * (1.0f / 27.0f);
   }
 }
 
@@ -413,28 +417,33 @@ __global__ __launch_bounds__(256) void trilinear_up2_bwd_kernel(const float* __r
   const int w = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y;
   const int d = blockIdx.z % Di;
   const long nc = blockIdx.z / Di;
-  if (w >= Wi) return;
   const int Ho = 2 * Hi, Wo = 2 * Wi;
-  const float* p = gy + nc * (2L * Di) * Ho * Wo;
+  const long plane = (2L * Di) * Ho * Wo;
+  const __amdgpu_buffer_rsrc_t gr = dca_rsrc(gy + nc * plane, plane * 4);
+  const int wok = (int)(w < Wi);
   float wd[4], wh[4], ww[4];
   up2_bwd_w(d, Di, wd); up2_bwd_w(h, Hi, wh); up2_bwd_w(w, Wi, ww);
+  // 16 rows x (one 8-byte + two 4-byte) predicated buffer loads, all independent; a zero weight means the sample
+  // is outside the tensor, and the masked load returns 0 for it
   float acc = 0.f;
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     const int od = 2 * d - 1 + a;
-    if (wd[a] == 0.f) continue;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const int oh = 2 * h - 1 + b;
-      if (wh[b] == 0.f) continue;
-      const float* row = p + ((long)od * Ho + oh) * Wo + 2 * w;
-      float r = ww[1] * row[0] + ww[2] * row[1];
-      if (ww[0] != 0.f) r += ww[0] * row[-1];
-      if (ww[3] != 0.f) r += ww[3] * row[2];
+      const int ok = wok & (int)(wd[a] != 0.f) & (int)(wh[b] != 0.f);
+      const int off = ((od * Ho + oh) * Wo + 2 * w) * 4;
+      const float2 mid = dca_bload2(gr, off, ok);
+      const float lo = dca_bload1(gr, off - 4, ok & (int)(ww[0] != 0.f));
+      const float hi = dca_bload1(gr, off + 8, ok & (int)(ww[3] != 0.f));
+      float r = ww[1] * mid.x + ww[2] * mid.y;
+      r += ww[0] * lo;
+      r += ww[3] * hi;
       acc += wd[a] * wh[b] * r;
     }
   }
-  gx[((nc * Di + d) * Hi + h) * Wi + w] = acc;
+  if (wok) gx[((nc * Di + d) * Hi + h) * Wi + w] = acc;
 }
 
 static int ew_grid(long total) {
@@ -507,16 +516,18 @@ extern "C" int dca_bn_backward(const float* dz, const float* y, const float* res
 extern "C" int dca_avgpool3d_fwd(const float* x, float* y, long NC, int Di, int Hi, int Wi, hipStream_t stream) {
   DCA_REQUIRE(x && y && NC > 0 && Di > 0 && Hi > 0 && Wi > 0);
   const int Do = (Di + 1) / 2, Ho = (Hi + 1) / 2, Wo = (Wi + 1) / 2;  // floor((i+2-3)/2)+1
-  hipLaunchKernelGGL(avgpool3d_fwd_kernel, dim3(ew_grid(NC * Do * Ho * Wo)), dim3(256), 0, stream, x, y, NC, Di, Hi,
-                     Wi, Do, Ho, Wo);
+  DCA_REQUIRE((long)Di * Hi * Wi * 4 < 0x7ffffff0L && NC * Do < 0x7fffffffL);  // 32-bit offsets inside one channel
+  hipLaunchKernelGGL(avgpool3d_fwd_kernel, dim3((unsigned)(NC * Do), cdiv((long)Ho * Wo, 1024)), dim3(256), 0, stream, x,
+                     y, Di, Hi, Wi, Do, Ho, Wo);
   return dca_launch_status();
 }
 
 extern "C" int dca_avgpool3d_bwd(const float* gy, float* gx, long NC, int Di, int Hi, int Wi, hipStream_t stream) {
   DCA_REQUIRE(gy && gx && NC > 0 && Di > 0 && Hi > 0 && Wi > 0);
   const int Do = (Di + 1) / 2, Ho = (Hi + 1) / 2, Wo = (Wi + 1) / 2;
-  hipLaunchKernelGGL(avgpool3d_bwd_kernel, dim3(ew_grid(NC * Di * Hi * Wi)), dim3(256), 0, stream, gy, gx, NC, Di, Hi,
-                     Wi, Do, Ho, Wo);
+  DCA_REQUIRE((long)Di * Hi * Wi * 4 < 0x7ffffff0L && NC * Di < 0x7fffffffL);
+  hipLaunchKernelGGL(avgpool3d_bwd_kernel, dim3((unsigned)(NC * Di), cdiv((long)Hi * Wi, 1024)), dim3(256), 0, stream, gy,
+                     gx, Di, Hi, Wi, Do, Ho, Wo);
   return dca_launch_status();
 }
 
@@ -536,7 +547,7 @@ extern "C" int dca_trilinear_fwd(const float* x, float* y, long NC, int Di, int 
 extern "C" int dca_trilinear_bwd(const float* gy, float* gx, long NC, int Di, int Hi, int Wi, int scale,
                                  hipStream_t stream) {
   DCA_REQUIRE(gy && gx && NC > 0 && Di > 0 && Hi > 0 && Wi > 0 && scale >= 1);
-  if (scale == 2 && Hi <= 65535 && NC * Di <= 65535) {
+  if (scale == 2 && Hi <= 65535 && NC * Di <= 65535 && 32L * Di * Hi * Wi < 0x7ffffff0L && (((uintptr_t)gy & 7) == 0)) {
     hipLaunchKernelGGL(trilinear_up2_bwd_kernel, dim3(cdiv(Wi, 256), Hi, (unsigned)(NC * Di)), dim3(256), 0, stream, gy, gx,
                        Di, Hi, Wi);
     return dca_launch_status();
