@@ -101,6 +101,22 @@ int dca_conv3d_wino_forward(const float* x, const float* ug, float* y, const flo
                             const float* res_pre, const float* res_post, float slope, int N, int Cin, int Cout,
                             int CinPad, int CoutTotal, int co_off, int D, int H, int W, hipStream_t stream);
 
+/* "bf16x3" split-precision 3x3x3 / stride-1 / pad-1 convolution (conv3d_bf16x3.hip): every fp32 operand is split exactly
+ * into three bf16 terms and the six partial products >= 2^-16 run on the bf16 matrix pipe with fp32 accumulation --
+ * fp32-grade results (dropped terms <= 2^-23 relative, no range restriction) at 2.67x fewer matrix-pipe cycles than
+ * the fp32 MFMA kernel.  Replaces the same nn.Conv3d calls as dca_conv3d_forward (models/submodule.py:121-124,
+ * models/augment/cva.py:13-55) and, with src_ab = 1 / flip = 1, their backward-data.
+ *   dca_conv3d_x3_weight_bytes(Cin, Cout): size of the pre-split weight image wx.
+ *   dca_conv3d_x3_prep_weight: w is the PyTorch weight; A contraction channels, B output channels;
+ *       src_ab ? w[a][b][27] : w[b][a][27]; flip reverses the tap order (backward-data).  wx 16-byte aligned.
+ *   dca_conv3d_x3_forward: y (N,Cout,D,H,W) = act((conv(x, w)) * scale[c] + shift[c] + res_pre) + res_post, the epilogue
+ *       contract of dca_conv3d_forward; any Cin / Cout (zero padded to 16 / 32 internally); Cin*D*H*W*4 < 2^31. */
+long dca_conv3d_x3_weight_bytes(int Cin, int Cout);
+int dca_conv3d_x3_prep_weight(const float* w, void* wx, int A, int B, int src_ab, int flip, hipStream_t stream);
+int dca_conv3d_x3_forward(const float* x, const void* wx, float* y, const float* scale, const float* shift,
+                          const float* res_pre, const float* res_post, float slope, int N, int Cin, int Cout, int D,
+                          int H, int W, hipStream_t stream);
+
 /* Single-output-channel 3x3x3 convolution (the logit heads: nn.Conv3d(32, 1, 3, padding=1, bias=False),
  * models/gwcnet_dca_g.py:154-168 `classif*.2`, models/augment/cva.py:51-53 `classify.2`).  w is the PyTorch weight
  * (1,C,3,3,3) as is.  The 27 taps become a GEMM axis so forward / weight gradient reuse the matrix-core kernels:
