@@ -22,6 +22,7 @@
 // channel chunk is three phases of 108 MFMAs per wave with one barrier each; the next slab / next halo tile are
 // fetched into registers (hardware-predicated buffer loads) while the current phase's MFMAs run.
 #include "dca_common.h"
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -34,8 +35,11 @@ constexpr int B_TERM = 2 * NVOX * 16;              // bytes of one bf16 term ima
 constexpr int B_BYTES = 3 * B_TERM;                // 103680
 constexpr int A_SLAB = 9 * 3 * 1024;               // 9 taps x 3 terms x (64 lanes x 16 B)
 constexpr int LDS_BYTES = B_BYTES + 2 * A_SLAB;    // 158976 of the CU's 163840
-constexpr int NB_ITEMS = 2 * NVOX;                 // (k half, voxel) staging items of 8 channels
+constexpr int NB_ITEMS = 2 * NVOX;                 // (k half, voxel) staging items of 8 channels (unaligned path)
 constexpr int KB = (NB_ITEMS + 511) / 512;         // 5
+constexpr int NROWS = 2 * ID * IH;                 // 120 (k half, d, h) halo rows: 4 aligned quads + 2 edge voxels each
+constexpr int NQUAD = NROWS * 4, NEDGE = NROWS * 2;  // aligned path: 480 quad items (8 x b128), 240 edge items (8 x b32)
+static_assert(NQUAD <= 512 && NEDGE <= 512, "one quad / edge item per thread");
 constexpr int NA_ITEMS = A_SLAB / 16;              // 1728 b128 per slab
 constexpr int KA = (NA_ITEMS + 511) / 512;         // 4
 
@@ -61,25 +65,19 @@ __device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l)
   l = (__bf16)r2;
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(512) void conv3_bf16x3_kernel(X3Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* b_lds = smem;
   char* a_lds = smem + B_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, half = lane >> 5;
-  int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tw = bid % a.nTW; bid /= a.nTW;
-  const int th = bid % a.nTH; bid /= a.nTH;
-  const int td = bid % a.nTD;
-  const int n = bid / a.nTD;
   const int cblk = blockIdx.y;
-  const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
-
-  f32x16 acc[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  // persistent: this workgroup owns the contiguous tile range [t_begin, t_end) (w fastest, so consecutive tiles share
+  // halo planes that are still in this XCD's L2) and runs the load / MFMA pipeline straight across tile boundaries
+  const long T = (long)a.N * a.nTD * a.nTH * a.nTW;
+  const int t_begin = (int)(T * blockIdx.x / gridDim.x), t_end = (int)(T * (blockIdx.x + 1) / gridDim.x);
+  if (t_begin >= t_end) return;
 
   // per-lane byte offset of the lane's voxel inside a term image, for its two column tiles
   int boff[2];
@@ -91,13 +89,12 @@ __global__ __launch_bounds__(512) void conv3_bf16x3_kernel(X3Args a) {
 
   const int cstride = a.D * a.H * a.W;
   const long sample = (long)a.Cin * cstride;
-  const __amdgpu_buffer_rsrc_t xr = dca_rsrc(a.x + (long)n * sample, sample * 4);
   const int P = a.NCH * 3;
   const long wbytes = (long)P * A_SLAB;
   const __amdgpu_buffer_rsrc_t wr = dca_rsrc((const char*)a.wx + (long)cblk * wbytes, wbytes);
 
+  const bool has_aff = a.scale != nullptr, has_pre = a.res_pre != nullptr, has_post = a.res_post != nullptr;
   float4 ra[KA];
-  float rb[KB][8];
   auto load_A = [&](int p) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < KA; ++k) {
@@ -112,125 +109,239 @@ __global__ __launch_bounds__(512) void conv3_bf16x3_kernel(X3Args a) {
       if (it < NA_ITEMS) *(float4*)(a_lds + buf * A_SLAB + it * 16) = ra[k];
     }
   };
-  auto load_B = [&](int chunk) __attribute__((always_inline)) {
+
+  // Staging of a chunk's halo tile, global -> registers (load_B) -> split -> LDS (store_B).
+  //  VEC (W % 4 == 0, 16-byte aligned x): a thread owns one aligned quad of 4 voxels along W (8 x b128, one per
+  //  channel of its k half) and, for tid < 240, one of the two edge voxels of a row (8 x b32): 16 loads per thread.
+  //  Otherwise: 5 single-voxel items of 8 x b32.
+  float4 rq[VEC ? 8 : 1];
+  float re[VEC ? 8 : 1];
+  float rb[VEC ? 1 : KB][8];
+  int item_crd[VEC ? 2 : KB];  // packed halo coordinates of the thread's items, fixed for the whole kernel
+  if constexpr (VEC) {
+    {
+      const int row = tid >> 2, q = tid & 3, kh = row / (ID * IH), rem = row - kh * (ID * IH), id = rem / IH, ih = rem - id * IH;
+      item_crd[0] = (tid < NQUAD) ? (id | (ih << 8) | ((1 + 4 * q) << 16) | (kh << 24)) : -1;
+    }
+    {
+      const int row = tid >> 1, side = tid & 1, kh = row / (ID * IH), rem = row - kh * (ID * IH), id = rem / IH, ih = rem - id * IH;
+      item_crd[1] = (tid < NEDGE) ? (id | (ih << 8) | ((side ? IW - 1 : 0) << 16) | (kh << 24)) : -1;
+    }
+  } else {
 #pragma unroll
     for (int k = 0; k < KB; ++k) {
       const int it = tid + 512 * k;
       const int kh = it / NVOX, v = it - kh * NVOX;
       const int id = v / (IH * IW), rem = v - id * (IH * IW), ih = rem / IW, iw = rem - ih * IW;
-      const int di = d0 - 1 + id, hi = h0 - 1 + ih, wi = w0 - 1 + iw;
-      const int okv = (int)(it < NB_ITEMS) & (int)((unsigned)di < (unsigned)a.D) & (int)((unsigned)hi < (unsigned)a.H) &
-                      (int)((unsigned)wi < (unsigned)a.W);
-      const int sp = (di * a.H + hi) * a.W + wi;
+      item_crd[k] = (it < NB_ITEMS) ? (id | (ih << 8) | (iw << 16) | (kh << 24)) : -1;
+    }
+  }
+  auto item_off = [&](int crd, int d0, int h0, int w0, int chunk, int& c0, int& okv) __attribute__((always_inline)) {
+    const int di = d0 - 1 + (crd & 255), hi = h0 - 1 + ((crd >> 8) & 255), wi = w0 - 1 + ((crd >> 16) & 255);
+    c0 = chunk * 16 + ((crd >> 24) & 1) * 8;
+    okv = (int)(crd >= 0) & (int)((unsigned)di < (unsigned)a.D) & (int)((unsigned)hi < (unsigned)a.H) &
+          (int)((unsigned)wi < (unsigned)a.W);
+    return (c0 * cstride + (di * a.H + hi) * a.W + wi) * 4;
+  };
+  auto load_B = [&](int n, int d0, int h0, int w0, int chunk) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t xr = dca_rsrc(a.x + (long)n * sample, sample * 4);
+    if constexpr (VEC) {
+      int c0, okv;
+      const int offq = item_off(item_crd[0], d0, h0, w0, chunk, c0, okv);  // a quad is inside W or outside as a whole
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int c = chunk * 16 + kh * 8 + j;
-        rb[k][j] = dca_bload1(xr, (c * cstride + sp) * 4, okv & (int)(c < a.Cin));
+      for (int j = 0; j < 8; ++j) rq[j] = dca_bload4(xr, offq + j * cstride * 4, okv & (int)(c0 + j < a.Cin));
+      const int offe = item_off(item_crd[1], d0, h0, w0, chunk, c0, okv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) re[j] = dca_bload1(xr, offe + j * cstride * 4, okv & (int)(c0 + j < a.Cin));
+    } else {
+#pragma unroll
+      for (int k = 0; k < KB; ++k) {
+        int c0, okv;
+        const int off = item_off(item_crd[k], d0, h0, w0, chunk, c0, okv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rb[k][j] = dca_bload1(xr, off + j * cstride * 4, okv & (int)(c0 + j < a.Cin));
       }
     }
+  };
+  auto split_store = [&](const float (&v)[8], int vox_off) __attribute__((always_inline)) {
+    bf16x8 hv, mv, lv;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      __bf16 h, m, l;
+      split3(v[j], h, m, l);
+      hv[j] = h; mv[j] = m; lv[j] = l;
+    }
+    *(bf16x8*)(b_lds + vox_off) = hv;
+    *(bf16x8*)(b_lds + B_TERM + vox_off) = mv;
+    *(bf16x8*)(b_lds + 2 * B_TERM + vox_off) = lv;
+  };
+  auto crd_lds = [&](int crd) __attribute__((always_inline)) {  // byte offset of the item's (first) voxel in a term image
+    return ((((crd >> 24) & 1) * ID + (crd & 255)) * IH + ((crd >> 8) & 255)) * IW * 16 + ((crd >> 16) & 255) * 16;
   };
   auto store_B = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int k = 0; k < KB; ++k) {
-      const int it = tid + 512 * k;
-      bf16x8 hv, mv, lv;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        __bf16 h, m, l;
-        split3(rb[k][j], h, m, l);
-        hv[j] = h; mv[j] = m; lv[j] = l;
+    if constexpr (VEC) {
+      if (item_crd[0] >= 0) {
+        const int o = crd_lds(item_crd[0]);
+        const float v0[8] = {rq[0].x, rq[1].x, rq[2].x, rq[3].x, rq[4].x, rq[5].x, rq[6].x, rq[7].x};
+        const float v1[8] = {rq[0].y, rq[1].y, rq[2].y, rq[3].y, rq[4].y, rq[5].y, rq[6].y, rq[7].y};
+        const float v2[8] = {rq[0].z, rq[1].z, rq[2].z, rq[3].z, rq[4].z, rq[5].z, rq[6].z, rq[7].z};
+        const float v3[8] = {rq[0].w, rq[1].w, rq[2].w, rq[3].w, rq[4].w, rq[5].w, rq[6].w, rq[7].w};
+        split_store(v0, o); split_store(v1, o + 16); split_store(v2, o + 32); split_store(v3, o + 48);
       }
-      if (it < NB_ITEMS) {
-        *(bf16x8*)(b_lds + it * 16) = hv;
-        *(bf16x8*)(b_lds + B_TERM + it * 16) = mv;
-        *(bf16x8*)(b_lds + 2 * B_TERM + it * 16) = lv;
+      if (item_crd[1] >= 0) {
+        const float v[8] = {re[0], re[1], re[2], re[3], re[4], re[5], re[6], re[7]};
+        split_store(v, crd_lds(item_crd[1]));
       }
+    } else {
+#pragma unroll
+      for (int k = 0; k < KB; ++k)
+        if (item_crd[k] >= 0) split_store(rb[k], crd_lds(item_crd[k]));
     }
   };
+  auto decode = [&](int tile, int& n, int& d0, int& h0, int& w0) __attribute__((always_inline)) {
+    const int tw = tile % a.nTW; tile /= a.nTW;
+    const int th = tile % a.nTH; tile /= a.nTH;
+    const int td = tile % a.nTD;
+    n = tile / a.nTD;
+    d0 = td * TD; h0 = th * TH; w0 = tw * TW;
+  };
 
-  load_B(0);
+  int n, d0, h0, w0;
+  decode(t_begin, n, d0, h0, w0);
+  load_B(n, d0, h0, w0, 0);
   load_A(0);
   store_B();
   store_A(0);
-  if (P > 1) load_A(1);
+  load_A(1);   // P >= 3
   __syncthreads();
 
+  int buf = 0;  // A slab buffer of the current phase (phases alternate buffers across chunk and tile boundaries)
 #pragma unroll 1
-  for (int p = 0; p < P; ++p) {
-    const int chunk = p / 3, kd = p - chunk * 3, buf = p & 1;
-    const bool next_chunk = (kd == 2) && (chunk + 1 < a.NCH);
-    if (p + 1 < P) store_A(buf ^ 1);  // slab p+1 (in registers since the previous phase) -> the buffer phase p-1 used
-    if (p + 2 < P) load_A(p + 2);
-    if (next_chunk) load_B(chunk + 1);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const bool more_tiles = tile + 1 < t_end;
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    int nn = n, nd0 = d0, nh0 = h0, nw0 = w0;  // coordinates of the next tile (valid when more_tiles)
 
-    const char* ab = a_lds + buf * A_SLAB + lane * 16;
-    const char* bb = b_lds + kd * (IH * IW * 16);
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int tap9 = kh * 3 + kw;
-        const bf16x8 ah = *(const bf16x8*)(ab + (tap9 * 3 + 0) * 1024);
-        const bf16x8 am = *(const bf16x8*)(ab + (tap9 * 3 + 1) * 1024);
-        const bf16x8 al = *(const bf16x8*)(ab + (tap9 * 3 + 2) * 1024);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const char* bp = bb + boff[t] + (kh * IW + kw) * 16;
-          const bf16x8 bh = *(const bf16x8*)(bp);
-          const bf16x8 bm = *(const bf16x8*)(bp + B_TERM);
-          const bf16x8 bl = *(const bf16x8*)(bp + 2 * B_TERM);
-          // smallest terms first
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+#pragma unroll 1
+    for (int p = 0; p < P; ++p, buf ^= 1) {
+      const int chunk = p / 3, kd = p - chunk * 3;
+      const bool last_of_chunk = kd == 2;
+      const bool next_chunk = last_of_chunk && (chunk + 1 < a.NCH);
+      const bool next_tile = last_of_chunk && !next_chunk && more_tiles;
+      // slab p+1 (in registers since the previous phase) -> the buffer phase p-1 used; then fetch slab p+2
+      if (p + 1 < P || more_tiles) store_A(buf ^ 1);
+      if (p + 2 < P || more_tiles) load_A(p + 2 < P ? p + 2 : p + 2 - P);
+      if (next_tile) decode(tile + 1, nn, nd0, nh0, nw0);
+      const bool stage = next_chunk || next_tile;  // fetch the halo tile of the next chunk / chunk 0 of the next tile
+      const char* ab = a_lds + buf * A_SLAB + lane * 16;
+      const char* bb = b_lds + kd * (IH * IW * 16);
+      // The 9 taps of the slab with a register double buffer: the 9 ds_read_b128 of tap+1 go one per MFMA between
+      // the 12 MFMAs of tap, and in a staging phase the global loads of the next halo tile are spread over the taps
+      // as well (all issued up front they fill the CU's memory queue and the waves sit in the issue stage for
+      // microseconds with the matrix pipe idle).  sched_group_barrier pins the order; left alone, hipcc issues each
+      // LDS read right before its first use and waits on it.
+      auto phase = [&](auto STAGE) __attribute__((always_inline)) {
+        constexpr bool ST = decltype(STAGE)::value;
+        constexpr int NLD = VEC ? 2 : 5;  // global loads per tap (8 taps): 16 / 40 per thread
+        if constexpr (ST) {
+          const bool nt = next_tile;
+          load_B(nt ? nn : n, nt ? nd0 : d0, nt ? nh0 : h0, nt ? nw0 : w0, nt ? 0 : chunk + 1);
         }
+        bf16x8 fa[2][3], fb[2][2][3];
+        auto load_frag = [&](int tap9, int slot) __attribute__((always_inline)) {
+          const int kh = tap9 / 3, kw = tap9 - kh * 3;
+#pragma unroll
+          for (int term = 0; term < 3; ++term) fa[slot][term] = *(const bf16x8*)(ab + (tap9 * 3 + term) * 1024);
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+              fb[slot][t][term] = *(const bf16x8*)(bb + boff[t] + (kh * IW + kw) * 16 + term * B_TERM);
+        };
+        load_frag(0, 0);
+#pragma unroll
+        for (int tap9 = 0; tap9 < 9; ++tap9) {
+          const int cur = tap9 & 1;
+          if (tap9 < 8) load_frag(tap9 + 1, cur ^ 1);
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            // smallest terms first
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][0], fb[cur][t][2], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][2], fb[cur][t][0], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][1], fb[cur][t][1], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][0], fb[cur][t][1], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][1], fb[cur][t][0], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][0], fb[cur][t][0], acc[t], 0, 0, 0);
+          }
+          if (tap9 < 8) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              if (ST && i < NLD) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+          }
+        }
+      };
+      if (stage) phase(std::true_type{}); else phase(std::false_type{});
+      if (stage) {
+        __syncthreads();  // every wave is done reading the halo tile of this chunk
+        store_B();
       }
+      __syncthreads();
     }
-    if (next_chunk) {
-      __syncthreads();  // every wave is done reading the halo tile of this chunk
-      store_B();
-    }
-    __syncthreads();
-  }
 
-  // Epilogue (same contract as conv3d_mfma.hip): y = act(acc * scale + shift + res_pre) + res_post
-  const bool has_aff = a.scale != nullptr, has_pre = a.res_pre != nullptr, has_post = a.res_post != nullptr;
-  float sc[16], sh[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int co = min(cblk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, a.Cout - 1);
-    sc[r] = has_aff ? a.scale[co] : 1.f;
-    sh[r] = has_aff ? a.shift[co] : 0.f;
-  }
-  const long plane = cstride;
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int r0 = (wv * 2 + t) * 2 + (l31 >> 4), d = d0 + (r0 >> 3), h = h0 + (r0 & 7), w = w0 + (l31 & 15);
-    const bool ok = d < a.D && h < a.H && w < a.W;
-    const long base = (long)n * a.Cout * plane + ((long)(ok ? d : 0) * a.H + (ok ? h : 0)) * a.W + (ok ? w : 0);
-    float rp[16], rq[16];
-    if (has_pre) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        rp[r] = a.res_pre[base + min(cblk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, a.Cout - 1) * plane];
-    }
-    if (has_post) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        rq[r] = a.res_post[base + min(cblk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, a.Cout - 1) * plane];
-    }
+    // Epilogue (same contract as conv3d_mfma.hip): y = act(acc * scale + shift + res_pre) + res_post.  The stores
+    // drain while the next tile's first phase runs.
+    // 32-bit offsets into this sample's output through buffer descriptors: nothing 64-bit for the compiler to hoist
+    // out of the tile loop (that cost ~60 spilled registers), and the bounds masks ride on the hardware range check.
+    const long osample = (long)a.Cout * cstride;
+    const __amdgpu_buffer_rsrc_t yr = dca_rsrc(a.y + (long)n * osample, osample * 4);
+    const __amdgpu_buffer_rsrc_t pr = dca_rsrc((has_pre ? a.res_pre : a.y) + (long)n * osample, osample * 4);
+    const __amdgpu_buffer_rsrc_t qr = dca_rsrc((has_post ? a.res_post : a.y) + (long)n * osample, osample * 4);
+    float sc[16], sh[16];  // (re)loaded per tile: holding them across the MFMA phases costs 32 registers
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int co = cblk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      float v = acc[t][r] * sc[r] + sh[r];
-      if (has_pre) v += rp[r];
-      v = act_apply(v, a.slope);
-      if (has_post) v += rq[r];
-      if (ok && co < a.Cout) a.y[base + co * plane] = v;
+      const int co = min(cblk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, a.Cout - 1);
+      sc[r] = has_aff ? a.scale[co] : 1.f;
+      sh[r] = has_aff ? a.shift[co] : 0.f;
     }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int r0 = (wv * 2 + t) * 2 + (l31 >> 4), d = d0 + (r0 >> 3), h = h0 + (r0 & 7), w = w0 + (l31 & 15);
+      const int ok = (int)(d < a.D) & (int)(h < a.H) & (int)(w < a.W);
+      const int voff = ((d * a.H + h) * a.W + w + (cblk * 32 + 4 * half) * cstride) * 4;
+      float rp[16], rq[16];
+      if (has_pre) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int cu = (r & 3) + 8 * (r >> 2);
+          rp[r] = dca_bload1(pr, voff + cu * cstride * 4, ok & (int)(cblk * 32 + cu + 4 * half < a.Cout));
+        }
+      }
+      if (has_post) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int cu = (r & 3) + 8 * (r >> 2);
+          rq[r] = dca_bload1(qr, voff + cu * cstride * 4, ok & (int)(cblk * 32 + cu + 4 * half < a.Cout));
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cu = (r & 3) + 8 * (r >> 2);
+        float v = acc[t][r] * sc[r] + sh[r];
+        if (has_pre) v += rp[r];
+        v = act_apply(v, a.slope);
+        if (has_post) v += rq[r];
+        dca_bstore1(yr, v, voff + cu * cstride * 4, ok & (int)(cblk * 32 + cu + 4 * half < a.Cout));
+      }
+    }
+    n = nn; d0 = nd0; h0 = nh0; w0 = nw0;
   }
 }
 
@@ -282,7 +393,7 @@ extern "C" int dca_conv3d_x3_forward(const float* x, const void* wx, float* y, c
                                      int D, int H, int W, hipStream_t stream) {
   DCA_REQUIRE(x && wx && y && N > 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0);
   DCA_REQUIRE((scale == nullptr) == (shift == nullptr));
-  DCA_REQUIRE((long)Cin * D * H * W * 4 < 0x7ffffff0L);  // 32-bit byte offsets inside one sample
+  DCA_REQUIRE((long)Cin * D * H * W * 4 < 0x7ffffff0L && (long)Cout * D * H * W * 4 < 0x7ffffff0L);  // 32-bit byte offsets inside one sample
   DCA_REQUIRE((((uintptr_t)wx) & 15) == 0);
   X3Args a;
   a.x = x; a.wx = (const unsigned short*)wx; a.y = y;
@@ -293,9 +404,21 @@ extern "C" int dca_conv3d_x3_forward(const float* x, const void* wx, float* y, c
   const long tiles = (long)N * a.nTD * a.nTH * a.nTW;
   DCA_REQUIRE(tiles < 0x7fffffffL && (Cout + 31) / 32 <= 65535);
   // per device, so not cached in a static
-  hipError_t e = hipFuncSetAttribute((const void*)conv3_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     LDS_BYTES);
+  const bool vec = (W % 4 == 0) && ((((uintptr_t)x) & 15) == 0);
+  auto kern = vec ? conv3_bf16x3_kernel<true> : conv3_bf16x3_kernel<false>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(conv3_bf16x3_kernel, dim3((unsigned)tiles, (Cout + 31) / 32), dim3(512), LDS_BYTES, stream, a);
+  // persistent: one workgroup per CU (the LDS footprint allows no more), each looping over its share of the tiles
+  const int cblks = (Cout + 31) / 32;
+  int ncu = 256;
+  {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      ncu = v;
+  }
+  int gx = ncu / cblks > 0 ? ncu / cblks : 1;
+  if (gx > tiles) gx = (int)tiles;
+  hipLaunchKernelGGL(kern, dim3(gx, cblks), dim3(512), LDS_BYTES, stream, a);
   return dca_launch_status();
 }

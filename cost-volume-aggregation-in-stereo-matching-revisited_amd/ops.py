@@ -206,6 +206,21 @@ def _round_up(a, m):
 WINOGRAD = os.environ.get("DCA_WINOGRAD", "0") == "1"
 
 
+# 3x3x3 stride-1 convolutions run on the bf16 matrix pipe with the exact three-way bf16 split of both operands
+# ("bf16x3", conv3d_bf16x3.hip): fp32-grade accuracy (measured error vs fp64 slightly BELOW the fp32 MFMA kernel's)
+# at ~1.36x the speed at 1/4 resolution.  DCA_CONV=fp32 forces the fp32 MFMA kernel everywhere.
+CONV_X3 = os.environ.get("DCA_CONV", "x3") != "fp32"
+_X3_MIN_WORKGROUPS = 192  # below this the persistent one-workgroup-per-CU kernel leaves most of the chip idle
+
+
+def _x3_eligible(x, x2, ksize, stride, transposed, A, B):
+    if not CONV_X3 or ksize != 3 or stride != 1 or transposed or x2 is not None:
+        return False
+    N, _, D, H, W = x.shape
+    tiles = N * ((D + 3) // 4) * ((H + 7) // 8) * ((W + 15) // 16) * ((B + 31) // 32)
+    return tiles >= _X3_MIN_WORKGROUPS and max(A, B) * D * H * W * 4 < 0x7ffffff0
+
+
 def _slice_width(ksize, stride, transposed, B):
     """output channels one launch of dca_conv3d_forward produces (include/dca_hip.h)"""
     if ksize == 1 or transposed:
@@ -255,6 +270,14 @@ def _conv_sliced(x, x2, w_src, A, B, K, src_ab, flip, ksize, stride, transposed,
         _chk(lib.dca_conv3d_wino_forward(_ptr(x), _ptr(ug), _ptr(y), _ptr(scale), _ptr(shift), _ptr(res_pre),
                                          _ptr(res_post), float(slope), N, A, B, Apad, B, 0, Di, Hi, Wi, _stream()),
              "dca_conv3d_wino_forward")
+        return y
+    if _x3_eligible(x, x2, ksize, stride, transposed, A, B):
+        wx = torch.empty((lib.dca_conv3d_x3_weight_bytes(A, B) // 2,), device=x.device, dtype=torch.int16)
+        _chk(lib.dca_conv3d_x3_prep_weight(_ptr(w_src), _ptr(wx), A, B, int(src_ab), int(flip), _stream()),
+             "dca_conv3d_x3_prep_weight")
+        _chk(lib.dca_conv3d_x3_forward(_ptr(x), _ptr(wx), _ptr(y), _ptr(scale), _ptr(shift), _ptr(res_pre),
+                                       _ptr(res_post), float(slope), N, A, B, Di, Hi, Wi, _stream()),
+             "dca_conv3d_x3_forward")
         return y
     for b0 in range(0, B, width):
         bn = min(width, B - b0)
