@@ -73,10 +73,14 @@ __global__ __launch_bounds__(512) void conv3_bf16x3_kernel(X3Args a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, half = lane >> 5;
   const int cblk = blockIdx.y;
-  // persistent: this workgroup owns the contiguous tile range [t_begin, t_end) (w fastest, so consecutive tiles share
-  // halo planes that are still in this XCD's L2) and runs the load / MFMA pipeline straight across tile boundaries
+  // persistent: the tile space (w fastest) is cut into one contiguous range per XCD (workgroups are dealt round-robin
+  // over the 8 XCDs, each with its own L2); inside its XCD's range, workgroup j of cnt takes tiles j, j + cnt, ... so
+  // at any time the CUs of an XCD work on neighbouring tiles and share their halos in that L2.  The load / MFMA
+  // pipeline runs straight across tile boundaries.
   const long T = (long)a.N * a.nTD * a.nTH * a.nTW;
-  const int t_begin = (int)(T * blockIdx.x / gridDim.x), t_end = (int)(T * (blockIdx.x + 1) / gridDim.x);
+  const int nx = gridDim.x >= 8 ? 8 : 1, xcd = blockIdx.x % nx;
+  const int cnt = (gridDim.x - xcd + nx - 1) / nx;          // workgroups on this XCD
+  const int t_begin = (int)(T * xcd / nx) + blockIdx.x / nx, t_end = (int)(T * (xcd + 1) / nx), t_step = cnt;
   if (t_begin >= t_end) return;
 
   // per-lane byte offset of the lane's voxel inside a term image, for its two column tiles
@@ -217,8 +221,8 @@ __global__ __launch_bounds__(512) void conv3_bf16x3_kernel(X3Args a) {
 
   int buf = 0;  // A slab buffer of the current phase (phases alternate buffers across chunk and tile boundaries)
 #pragma unroll 1
-  for (int tile = t_begin; tile < t_end; ++tile) {
-    const bool more_tiles = tile + 1 < t_end;
+  for (int tile = t_begin; tile < t_end; tile += t_step) {
+    const bool more_tiles = tile + t_step < t_end;
     f32x16 acc[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(512) void conv3_bf16x3_kernel(X3Args a) {
       // slab p+1 (in registers since the previous phase) -> the buffer phase p-1 used; then fetch slab p+2
       if (p + 1 < P || more_tiles) store_A(buf ^ 1);
       if (p + 2 < P || more_tiles) load_A(p + 2 < P ? p + 2 : p + 2 - P);
-      if (next_tile) decode(tile + 1, nn, nd0, nh0, nw0);
+      if (next_tile) decode(tile + t_step, nn, nd0, nh0, nw0);
       const bool stage = next_chunk || next_tile;  // fetch the halo tile of the next chunk / chunk 0 of the next tile
       const char* ab = a_lds + buf * A_SLAB + lane * 16;
       const char* bb = b_lds + kd * (IH * IW * 16);

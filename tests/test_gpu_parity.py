@@ -163,6 +163,72 @@ def test_conv3d(case):
     close_l2(gw, gwr, 1e-5, "dw"); close(gw, gwr, 2e-5, "dw")
 
 
+X3_CASES = [
+    # cin, cout, dims, N   (W % 4 == 0 -> aligned quad staging; otherwise the single-voxel staging)
+    (40, 32, (4, 6, 10), 2),
+    (32, 32, (5, 10, 68), 1),
+    (32, 27, (3, 9, 36), 1),
+    (64, 64, (4, 8, 40), 1),
+    (16, 33, (5, 9, 17), 2),
+    (128, 128, (2, 4, 6), 1),
+    (48, 32, (9, 17, 33), 1),
+]
+
+
+@pytest.mark.parametrize("case", X3_CASES, ids=[str(c) for c in X3_CASES])
+def test_conv3d_bf16x3_path(case, monkeypatch):
+    """the bf16x3 split kernel (conv3d_bf16x3.hip) that serves the large 3x3x3 stride-1 convolutions: forward and,
+    through autograd, backward-data, at the same tolerance as the fp32 MFMA kernel"""
+    _, ops = _mods()
+    monkeypatch.setattr(ops, "CONV_X3", True)
+    monkeypatch.setattr(ops, "_X3_MIN_WORKGROUPS", 1)
+    cin, cout, dims, N = case
+    x = seeded_tensor(f"x3.x{case}", (N, cin) + dims)
+    w = seeded_tensor(f"x3.w{case}", (cout, cin, 3, 3, 3)) * (1.0 / (cin * 27) ** 0.5)
+    xc, wc = cpu_leaf(x), cpu_leaf(w)
+    yr = F.conv3d(xc, wc, None, 1, 1)
+    gy = seeded_tensor(f"x3.g{case}", yr.shape)
+    gxr, gwr = torch.autograd.grad((yr * gy).sum(), [xc, wc])
+    xg, wg = gpu(x, True), gpu(w, True)
+    y = ops.conv3d(xg, wg, 1, False)
+    gx, gw = torch.autograd.grad((y * gy.to(DEV)).sum(), [xg, wg])
+    close(y, yr, 1e-5, "fwd"); close(gx, gxr, 1e-5, "dx"); close_l2(gw, gwr, 1e-5, "dw")
+
+
+def test_conv3d_bf16x3_is_fp32_grade(monkeypatch):
+    """against an fp64 convolution the split kernel must be as accurate as the fp32 MFMA kernel (it drops only
+    partial products below 2^-23 relative), including for operands spanning many binades"""
+    _, ops = _mods()
+    monkeypatch.setattr(ops, "_X3_MIN_WORKGROUPS", 1)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(1, 32, 6, 12, 32, generator=g) * torch.exp2(torch.randint(-12, 12, (1, 32, 6, 12, 32), generator=g).float())
+    w = torch.randn(32, 32, 3, 3, 3, generator=g) * torch.exp2(torch.randint(-6, 6, (32, 32, 3, 3, 3), generator=g).float())
+    ref = F.conv3d(x.double(), w.double(), None, 1, 1)
+    xg, wg = x.to(DEV), w.to(DEV)
+    monkeypatch.setattr(ops, "CONV_X3", True)
+    e_x3 = (ops.conv3d(xg, wg, 1, False).cpu().double() - ref).abs().max().item()
+    monkeypatch.setattr(ops, "CONV_X3", False)
+    e_f32 = (ops.conv3d(xg, wg, 1, False).cpu().double() - ref).abs().max().item()
+    e_cpu = (F.conv3d(x, w, None, 1, 1).double() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert e_x3 <= 2.0 * max(e_f32, e_cpu) and e_x3 <= 2e-6 * scale, (e_x3, e_f32, e_cpu, scale)
+
+
+def test_conv3d_bf16x3_fused_epilogue(monkeypatch):
+    """y = act(conv * scale + shift + res_pre) + res_post through the C ABI of the split kernel"""
+    _, ops = _mods()
+    N, cin, cout, dims = 2, 32, 40, (5, 9, 20)
+    x = seeded_tensor("x3e.x", (N, cin) + dims); w = seeded_tensor("x3e.w", (cout, cin, 3, 3, 3)) * 0.05
+    sc = seeded_tensor("x3e.s", (cout,)).abs() + 0.5; sh = seeded_tensor("x3e.b", (cout,))
+    rp = seeded_tensor("x3e.p", (N, cout) + dims); rq = seeded_tensor("x3e.q", (N, cout) + dims)
+    ref = F.leaky_relu(F.conv3d(x, w, None, 1, 1) * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1) + rp, 0.1) + rq
+    monkeypatch.setattr(ops, "CONV_X3", True)
+    monkeypatch.setattr(ops, "_X3_MIN_WORKGROUPS", 1)
+    y = ops._conv_sliced(x.to(DEV), None, w.to(DEV), cin, cout, 27, 0, 0, 3, 1, False, sc.to(DEV), sh.to(DEV), 0.1,
+                         rp.to(DEV), rq.to(DEV))
+    close(y, ref, 1e-5, "fused")
+
+
 @pytest.mark.parametrize("case", [(40, 32, (4, 6, 10), 2), (32, 32, (5, 10, 68), 1), (32, 27, (3, 9, 36), 1), (64, 32, (4, 8, 40), 1)])
 def test_conv3d_winograd_path(case, monkeypatch):
     """the opt-in Winograd F(2x2,3x3)xD kernel (forward and, through autograd, stride-1 backward-data)"""
