@@ -208,9 +208,10 @@ WINOGRAD = os.environ.get("DCA_WINOGRAD", "0") == "1"
 
 # 3x3x3 stride-1 convolutions run on the bf16 matrix pipe with the exact three-way bf16 split of both operands
 # ("bf16x3", conv3d_bf16x3.hip): fp32-grade accuracy (measured error vs fp64 slightly BELOW the fp32 MFMA kernel's)
-# at ~1.36x the speed at 1/4 resolution.  DCA_CONV=fp32 forces the fp32 MFMA kernel everywhere.
+# at 1.3-1.75x the speed on every shape the networks use, 1/4 to 1/16 resolution (tools/x3_vs_fp32.py).
+# DCA_CONV=fp32 forces the fp32 MFMA kernel everywhere.
 CONV_X3 = os.environ.get("DCA_CONV", "x3") != "fp32"
-_X3_MIN_WORKGROUPS = 192  # below this the persistent one-workgroup-per-CU kernel leaves most of the chip idle
+_X3_MIN_WORKGROUPS = 1
 
 
 def _x3_eligible(x, x2, ksize, stride, transposed, A, B):

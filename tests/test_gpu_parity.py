@@ -141,9 +141,15 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("x3", [False, True], ids=["fp32mfma", "bf16x3"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[str(c[:5]) + str(c[5]) for c in CONV_CASES])
-def test_conv3d(case):
+def test_conv3d(case, x3, monkeypatch):
+    """x3 = False: the fp32 MFMA kernels everywhere; True: 3x3x3 stride-1 forward / backward-data on the bf16x3 split
+    kernel (the shipped default), everything else unchanged"""
     _, ops = _mods()
+    monkeypatch.setattr(ops, "CONV_X3", x3)
+    if x3 and not (case[2] == 3 and case[3] == 1 and not case[4] and case[1] > 1):
+        pytest.skip("the bf16x3 kernel serves 3x3x3 stride-1 convolutions only")
     cin, cout, k, stride, transposed, dims, N = case
     x = seeded_tensor(f"cv.x{case}", (N, cin) + dims)
     wshape = (cin, cout, k, k, k) if transposed else (cout, cin, k, k, k)

@@ -1,0 +1,21 @@
+"""Per-step kernel time breakdown from a rocprofv3 kernel_trace.csv of bench.py (one step window: between the last
+two gwc_fwd launches, so MIOpen find-mode / warm-up kernels do not pollute the totals).
+    python tools/step_breakdown.py gpurun_out/prof/.../NNN_kernel_trace.csv [top]"""
+import collections
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+top = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+idx = [i for i, r in enumerate(rows) if "gwc_fwd" in r["Kernel_Name"]]
+a, b = idx[-2], idx[-1]
+win = rows[a:b]
+tot, cnt = collections.Counter(), collections.Counter()
+for r in win:
+    n = r["Kernel_Name"].split("(")[0][:64]
+    tot[n] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); cnt[n] += 1
+wall = int(win[-1]["End_Timestamp"]) - int(win[0]["Start_Timestamp"])
+print("steps found %d; window wall %.2f ms, kernel sum %.2f ms, launches %d" % (len(idx), wall / 1e6, sum(tot.values()) / 1e6, len(win)))
+for n, t in tot.most_common(top):
+    print("  %-66s %4d %8.3f ms" % (n, cnt[n], t / 1e6))
