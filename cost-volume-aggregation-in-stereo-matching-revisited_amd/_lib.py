@@ -26,6 +26,8 @@ SIGNATURES = {
     "dca_conv3d_x3_prep_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "dca_conv3d_x3_forward": (_i, [_p] * 7 + [_f] + [_i] * 6 + [_p]),
     "dca_conv3d_wgrad_workspace": (_l, [_i] * 8),
+    "dca_conv3d_wgrad_x3_workspace": (_l, [_i] * 6),
+    "dca_conv3d_wgrad_x3": (_i, [_p, _p, _p, _p] + [_i] * 6 + [_l, _l, _p]),
     "dca_conv3d_wgrad": (_i, [_p, _p, _p, _p] + [_i] * 11 + [_l, _l, _p]),
     "dca_conv3d_c1_gather": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "dca_conv3d_c1_expand": (_i, [_p, _p, _i, _i, _i, _i, _p]),

@@ -290,6 +290,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// shared with conv3d_wgrad_bf16x3.hip (same slab format)
+int dca_internal_wgrad_reduce(const float* part, float* dw, int nblk, int nCxT, int nCT, int K, int Cy, int Cx,
+                              long s_cy, long s_cx, hipStream_t stream) {
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((long)nCT * K * 1024, 64)), dim3(256), 0, stream, part, dw, nblk,
+                     nCxT, nCT, K, Cy, Cx, s_cy, s_cx);
+  return dca_launch_status();
+}
+
 static int wg_workers(int ntiles, int nCT) {
   int w = 256 / nCT;
   if (w < 1) w = 1;

@@ -331,11 +331,19 @@ def _wgrad(x, dy, dw_view_ptr_tensor, dst_offset, Cx, Cy, ksize, stride, s_cy, s
     N = x.shape[0]
     Di, Hi, Wi = x.shape[2:]
     Do, Ho, Wo = dy.shape[2:]
-    nws = _L().dca_conv3d_wgrad_workspace(N, Cx, Cy, Do, Ho, Wo, ksize, stride)
-    part = torch.empty((nws,), device=x.device, dtype=torch.float32)
     dst = _vp(dw_view_ptr_tensor.data_ptr() + 4 * dst_offset)
-    _chk(_L().dca_conv3d_wgrad(_ptr(x), _ptr(dy), _ptr(part), dst, N, Cx, Cy, Di, Hi, Wi, Do, Ho, Wo, ksize, stride,
-                               s_cy, s_cx, _stream()), "dca_conv3d_wgrad")
+    lib = _L()
+    if (CONV_X3 and ksize == 3 and stride == 1 and Wi % 4 == 0 and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0
+            and max(Cx, Cy) * Di * Hi * Wi * 4 < 0x7ffffff0):
+        nws = lib.dca_conv3d_wgrad_x3_workspace(N, Cx, Cy, Di, Hi, Wi)
+        part = torch.empty((nws,), device=x.device, dtype=torch.float32)
+        _chk(lib.dca_conv3d_wgrad_x3(_ptr(x), _ptr(dy), _ptr(part), dst, N, Cx, Cy, Di, Hi, Wi, s_cy, s_cx, _stream()),
+             "dca_conv3d_wgrad_x3")
+        return
+    nws = lib.dca_conv3d_wgrad_workspace(N, Cx, Cy, Do, Ho, Wo, ksize, stride)
+    part = torch.empty((nws,), device=x.device, dtype=torch.float32)
+    _chk(lib.dca_conv3d_wgrad(_ptr(x), _ptr(dy), _ptr(part), dst, N, Cx, Cy, Di, Hi, Wi, Do, Ho, Wo, ksize, stride,
+                              s_cy, s_cx, _stream()), "dca_conv3d_wgrad")
 
 
 class _Conv3dC1(torch.autograd.Function):

@@ -117,6 +117,15 @@ int dca_conv3d_x3_forward(const float* x, const void* wx, float* y, const float*
                           const float* res_pre, const float* res_post, float slope, int N, int Cin, int Cout, int D,
                           int H, int W, hipStream_t stream);
 
+/* Weight gradient of the 3x3x3 / stride-1 / pad-1 convolution on the bf16 matrix pipe with the same exact three-way
+ * bf16 split (conv3d_wgrad_bf16x3.hip); replaces dca_conv3d_wgrad for ksize 3, stride 1 (autograd's dW of the nn.Conv3d
+ * calls above).  dw[cy*s_cy + cx*s_cx + tap] = sum_{n,voxels} dy[n][cy] * x[n][cx] shifted by the tap; x (N,Cx,D,H,W),
+ * dy (N,Cy,D,H,W); part = scratch of dca_conv3d_wgrad_x3_workspace floats.  Requires W % 4 == 0 and 16-byte aligned
+ * x / dy (hipErrorInvalidValue otherwise: callers use dca_conv3d_wgrad).  Deterministic, no atomics. */
+long dca_conv3d_wgrad_x3_workspace(int N, int Cx, int Cy, int D, int H, int W);
+int dca_conv3d_wgrad_x3(const float* x, const float* dy, float* part, float* dw, int N, int Cx, int Cy, int D, int H,
+                        int W, long s_cy, long s_cx, hipStream_t stream);
+
 /* Single-output-channel 3x3x3 convolution (the logit heads: nn.Conv3d(32, 1, 3, padding=1, bias=False),
  * models/gwcnet_dca_g.py:154-168 `classif*.2`, models/augment/cva.py:51-53 `classify.2`).  w is the PyTorch weight
  * (1,C,3,3,3) as is.  The 27 taps become a GEMM axis so forward / weight gradient reuse the matrix-core kernels:

