@@ -127,9 +127,21 @@ def kernel_roofline(device):
                           PEAK_FP32_MFMA_TFLOPS, lambda: ops.conv3d_wino_prepared(x, ug, 32, 32, 32)))
         cases.append(("conv3_mfma_kernel<S1,Cout32,CK8,tile 4x8x16> (3x3x3 32->32 @1/4 res, fp32 MFMA)", "conv3_mfma",
                       PEAK_FP32_MFMA_TFLOPS, lambda: ops.conv3d_prepared(x, wt, 32, cpad, 32, 3, 1, False)))
+        def run_wgrad(x3):
+            def f():
+                keep = ops.CONV_X3
+                ops.CONV_X3 = x3
+                try:
+                    ops._wgrad(x, x, wgt.new_empty(wgt.shape), 0, 32, 32, 3, 1, 32 * 27, 27)
+                finally:
+                    ops.CONV_X3 = keep
+            return f
+
+        if ops.CONV_X3:
+            cases.append(("wgrad3_bf16x3_kernel (+reduce) (dW of 3x3x3 32->32 @1/4 res; same 6-product bf16 split)",
+                          "wgrad3_bf16x3", PEAK_BF16_MFMA_TFLOPS / 6.0, run_wgrad(True)))
         cases.append(("wgrad3_kernel<S1> (+reduce) (dW of 3x3x3 32->32 @1/4 res, fp32 MFMA)", "wgrad3",
-                      PEAK_FP32_MFMA_TFLOPS,
-                      lambda: ops._wgrad(x, x, wgt.new_empty(wgt.shape), 0, 32, 32, 3, 1, 32 * 27, 27)))
+                      PEAK_FP32_MFMA_TFLOPS, run_wgrad(False)))
         for name, key, peak, fn in cases:
             for _ in range(2):
                 fn()
@@ -146,7 +158,7 @@ def kernel_roofline(device):
             out[name] = {"bound": "mfma", "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(tf / peak, 4), "traffic": None, "ms_per_launch": round(ms, 4),
                          "flop_per_launch": flops, "pmc_key": key}
-            if key == "conv3_bf16x3":
+            if key in ("conv3_bf16x3", "wgrad3_bf16x3"):
                 out[name]["peak_note"] = "dense bf16 MFMA peak (2500) / 6 products per fp32 product"
                 out[name]["executed_bf16"] = {"achieved": round(6 * tf, 1), "peak": PEAK_BF16_MFMA_TFLOPS,
                                               "unit": "TFLOP/s", "frac": round(6 * tf / PEAK_BF16_MFMA_TFLOPS, 4)}

@@ -12,7 +12,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-KEYS = {"conv3_bf16x3_kernel": "conv3_bf16x3", "conv3_mfma_kernel<1, 1, 8, 4, 8, 16, true>": "conv3_mfma",
+KEYS = {"conv3_bf16x3_kernel": "conv3_bf16x3", "wgrad3_bf16x3_kernel": "wgrad3_bf16x3", "conv3_mfma_kernel<1, 1, 8, 4, 8, 16, true>": "conv3_mfma",
         "wgrad3_kernel<1, 16>": "wgrad3"}
 ALGO_BYTES = 2 * 32 * 48 * 136 * 240 * 4 + 27 * 32 * 32 * 4   # read x + write y (or read x, dy) + weights
 
