@@ -208,8 +208,10 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(WgArgs a) {
   }
 }
 
-// 1x1x1: dW[cy][cx] = sum_v dy[cy][v] x[cx][v]; tile = 256 voxels, each wave contracts 64 of them.
-__global__ __launch_bounds__(256, 1) void wgrad1_kernel(WgArgs a) {
+// 1x1x1: dW[cy][cx] = sum_v dy[cy][v] x[cx][v]; tile = 256 voxels, each wave contracts 64 of them.  HBM-bound (reads x
+// and dy once): two workgroups per CU, and on aligned inputs the next tile's 2 x 32 KB are fetched into registers by
+// predicated buffer loads while the current tile's MFMAs run.
+__global__ __launch_bounds__(256, 2) void wgrad1_kernel(WgArgs a) {
   constexpr int NV = 256, P = NV + 1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xs = smem;
@@ -219,40 +221,61 @@ __global__ __launch_bounds__(256, 1) void wgrad1_kernel(WgArgs a) {
   const int cy0 = cyT * 32, cx0 = cxT * 32;
   const long DHW = (long)a.Do * a.Ho * a.Wo;
   const long tiles_per_n = (DHW + NV - 1) / NV;
+  const long ntile = (long)a.N * tiles_per_n;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (long tile = blockIdx.x; tile < (long)a.N * tiles_per_n; tile += gridDim.x) {
-    const int n = (int)(tile / tiles_per_n);
-    const long v0 = (tile % tiles_per_n) * NV;
-    __syncthreads();
-    if (a.vecx) {
-      for (int it = tid; it < 32 * 64; it += 256) {
-        const int q = it & 63, c = it >> 6;
-        const long v = v0 + 4 * q;
-        float4 vx = make_float4(0.f, 0.f, 0.f, 0.f), vy = vx;
-        if (v < DHW) {
-          if (cx0 + c < a.Cx) vx = *(const float4*)(a.x + ((long)n * a.Cx + cx0 + c) * DHW + v);
-          if (cy0 + c < a.Cy) vy = *(const float4*)(a.dy + ((long)n * a.Cy + cy0 + c) * DHW + v);
-        }
+  const bool pipelined = a.vecx && a.small_offsets;   // 32-bit byte offsets inside the whole tensors
+  if (pipelined) {
+    const __amdgpu_buffer_rsrc_t xr = dca_rsrc(a.x, (long)a.N * a.Cx * DHW * 4);
+    const __amdgpu_buffer_rsrc_t yr = dca_rsrc(a.dy, (long)a.N * a.Cy * DHW * 4);
+    float4 rx[8], ry[8];
+    auto load_regs = [&](long tile) __attribute__((always_inline)) {
+      const int n = (int)(tile / tiles_per_n);
+      const int v0 = (int)((tile % tiles_per_n) * NV);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int it = tid + 256 * k, q = it & 63, c = it >> 6;
+        const int v = v0 + 4 * q, ok = (int)(v < DHW);
+        rx[k] = dca_bload4(xr, (int)((((long)n * a.Cx + cx0 + c) * DHW + v) * 4), ok & (int)(cx0 + c < a.Cx));
+        ry[k] = dca_bload4(yr, (int)((((long)n * a.Cy + cy0 + c) * DHW + v) * 4), ok & (int)(cy0 + c < a.Cy));
+      }
+    };
+    if ((long)blockIdx.x < ntile) load_regs(blockIdx.x);
+    for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int it = tid + 256 * k, q = it & 63, c = it >> 6;
         float* dx = xs + c * P + 4 * q;
         float* dyp = ys + c * P + 4 * q;
-        dx[0] = vx.x; dx[1] = vx.y; dx[2] = vx.z; dx[3] = vx.w;
-        dyp[0] = vy.x; dyp[1] = vy.y; dyp[2] = vy.z; dyp[3] = vy.w;
+        dx[0] = rx[k].x; dx[1] = rx[k].y; dx[2] = rx[k].z; dx[3] = rx[k].w;
+        dyp[0] = ry[k].x; dyp[1] = ry[k].y; dyp[2] = ry[k].z; dyp[3] = ry[k].w;
       }
-    } else {
+      __syncthreads();
+      if (tile + gridDim.x < ntile) load_regs(tile + gridDim.x);
+      const float* xr_ = xs + l31 * P + wv * 64 + half;
+      const float* yr_ = ys + l31 * P + wv * 64 + half;
+#pragma unroll 8
+      for (int p = 0; p < 32; ++p) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(yr_[2 * p], xr_[2 * p], acc, 0, 0, 0);
+    }
+  } else {
+    for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+      const int n = (int)(tile / tiles_per_n);
+      const long v0 = (tile % tiles_per_n) * NV;
+      __syncthreads();
       for (int it = tid; it < 32 * NV; it += 256) {
         const int vl = it & 255, c = it >> 8;
         const long v = v0 + vl;
         xs[c * P + vl] = (v < DHW && cx0 + c < a.Cx) ? a.x[((long)n * a.Cx + cx0 + c) * DHW + v] : 0.f;
         ys[c * P + vl] = (v < DHW && cy0 + c < a.Cy) ? a.dy[((long)n * a.Cy + cy0 + c) * DHW + v] : 0.f;
       }
-    }
-    __syncthreads();
-    const float* xr = xs + l31 * P + wv * 64 + half;
-    const float* yr = ys + l31 * P + wv * 64 + half;
+      __syncthreads();
+      const float* xr_ = xs + l31 * P + wv * 64 + half;
+      const float* yr_ = ys + l31 * P + wv * 64 + half;
 #pragma unroll 8
-    for (int p = 0; p < 32; ++p) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(yr[2 * p], xr[2 * p], acc, 0, 0, 0);
+      for (int p = 0; p < 32; ++p) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(yr_[2 * p], xr_[2 * p], acc, 0, 0, 0);
+    }
   }
   // reduce the 4 waves through LDS, then one slab per workgroup
   __syncthreads();
@@ -266,22 +289,33 @@ __global__ __launch_bounds__(256, 1) void wgrad1_kernel(WgArgs a) {
 }
 
 // dw[cy*s_cy + cx*s_cx + tap] = sum_blk part[((blk*nCT + ct)*K + tap)*1024 + (cy%32)*32 + cx%32]
-// Threads walk the slab in memory order (coalesced); 4 thread groups split the slabs and meet in LDS, always
-// summing in the same order (deterministic).
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                           int nblk, int nCxT, int nCT, int K, int Cy, int Cx,
-                                                           long s_cy, long s_cx) {
-  __shared__ float red[4][64];
+// Threads walk the slab in memory order (coalesced); 16 thread groups split the slabs (8 independent loads in flight
+// per thread) and meet in LDS, always summing in the same order (deterministic).
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                            int nblk, int nCxT, int nCT, int K, int Cy, int Cx,
+                                                            long s_cy, long s_cx) {
+  __shared__ float red[16][64];
   const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
   const long slab_elems = (long)nCT * K * 1024;
   const long idx = (long)blockIdx.x * 64 + e;   // element inside one worker's slab set
   float s = 0.f;
-  if (idx < slab_elems)
-    for (int b = g; b < nblk; b += 4) s += part[(long)b * slab_elems + idx];
+  if (idx < slab_elems) {
+    int b = g;
+    for (; b + 7 * 16 < nblk; b += 8 * 16) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = part[(long)(b + 16 * j) * slab_elems + idx];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; b < nblk; b += 16) s += part[(long)b * slab_elems + idx];
+  }
   red[g][e] = s;
   __syncthreads();
   if (g == 0 && idx < slab_elems) {
-    const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v += red[j][e];
     const int cxl = idx & 31, cyl = (idx >> 5) & 31;
     const long t = idx >> 10;
     const int tap = t % K, ct = t / K;
@@ -293,13 +327,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // shared with conv3d_wgrad_bf16x3.hip (same slab format)
 int dca_internal_wgrad_reduce(const float* part, float* dw, int nblk, int nCxT, int nCT, int K, int Cy, int Cx,
                               long s_cy, long s_cx, hipStream_t stream) {
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((long)nCT * K * 1024, 64)), dim3(256), 0, stream, part, dw, nblk,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((long)nCT * K * 1024, 64)), dim3(1024), 0, stream, part, dw, nblk,
                      nCxT, nCT, K, Cy, Cx, s_cy, s_cx);
   return dca_launch_status();
 }
 
-static int wg_workers(int ntiles, int nCT) {
-  int w = 256 / nCT;
+static int wg_workers(int ntiles, int nCT, int per_cu = 1) {
+  int w = 256 * per_cu / nCT;
   if (w < 1) w = 1;
   return ntiles < w ? ntiles : w;
 }
@@ -329,7 +363,7 @@ extern "C" long dca_conv3d_wgrad_workspace(int N, int Cx, int Cy, int Do, int Ho
   wg_geometry(ksize, stride, N, Do, Ho, Wo, &nTD, &nTH, &nTW, &ntiles);
   const int nCT = cdiv(Cx, 32) * cdiv(Cy, 32);
   const int K = ksize == 1 ? 1 : 27;
-  return (long)wg_workers((int)(ntiles < 65535 ? ntiles : 65535), nCT) * nCT * K * 1024;
+  return (long)wg_workers((int)(ntiles < 65535 ? ntiles : 65535), nCT, ksize == 1 ? 2 : 1) * nCT * K * 1024;
 }
 
 extern "C" int dca_conv3d_wgrad(const float* x, const float* dy, float* part, float* dw, int N, int Cx, int Cy, int Di,
@@ -351,7 +385,7 @@ extern "C" int dca_conv3d_wgrad(const float* x, const float* dy, float* part, fl
   a.nCxT = cdiv(Cx, 32);
   const int nCT = a.nCxT * cdiv(Cy, 32);
   const int K = ksize == 1 ? 1 : 27;
-  const int nblk = wg_workers((int)(ntiles < 65535 ? ntiles : 65535), nCT);
+  const int nblk = wg_workers((int)(ntiles < 65535 ? ntiles : 65535), nCT, ksize == 1 ? 2 : 1);
   const dim3 grid(nblk, nCT);
   if (ksize == 1) {
     const long DHW = (long)Do * Ho * Wo;
@@ -385,7 +419,7 @@ extern "C" int dca_conv3d_wgrad(const float* x, const float* dy, float* part, fl
   }
   int st = dca_launch_status();
   if (st) return st;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((long)nCT * K * 1024, 64)), dim3(256), 0, stream, part, dw, nblk,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((long)nCT * K * 1024, 64)), dim3(1024), 0, stream, part, dw, nblk,
                      a.nCxT, nCT, K, Cy, Cx, s_cy, s_cx);
   return dca_launch_status();
 }

@@ -86,6 +86,10 @@ class GwcNet(nn.Module):
         return cost.squeeze(1)
 
     def hot_path(self, gwc_left, gwc_right, concat_left=None, concat_right=None):
+        with ops.batched_bn_counters():   # one multi-tensor add for all BatchNorm step counters
+            return self._hot_path(gwc_left, gwc_right, concat_left, concat_right)
+
+    def _hot_path(self, gwc_left, gwc_right, concat_left=None, concat_right=None):
         """reference gwcnet.py:194-238 from the 1/4-res features."""
         d = self.maxdisp // 4
         volume = build_gwc_volume(gwc_left, gwc_right, d, self.num_groups)

@@ -118,6 +118,10 @@ class GwcNet(nn.Module):
 
     # ---- the hot path proper: 1/4-res features -> 1/4-res disparity (+ training heads)
     def hot_path(self, gwc_left, gwc_right, concat_left=None, concat_right=None):
+        with ops.batched_bn_counters():   # one multi-tensor add for all BatchNorm step counters
+            return self._hot_path(gwc_left, gwc_right, concat_left, concat_right)
+
+    def _hot_path(self, gwc_left, gwc_right, concat_left=None, concat_right=None):
         """reference gwcnet_dca_g.py:216-239 (+ :244-275 when training).  Returns a dict with `pred4_q`
         (B,1,H/4,W/4) in 1/4-res pixels, `prob_volume2` and, in training mode, the auxiliary heads."""
         d = self.maxdisp // 4

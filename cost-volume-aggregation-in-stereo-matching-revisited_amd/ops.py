@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 from typing import Optional
 
 import torch
@@ -534,6 +535,25 @@ class _BnAct(torch.autograd.Function):
         return dy, dgb[:C], dgb[C:2 * C], None, None, None, None, None, None, g_pre, g_post
 
 
+_tls = threading.local()
+
+
+class batched_bn_counters:
+    """Inside this context the `num_batches_tracked += 1` of every train-mode BatchNorm (nn.BatchNorm3d semantics) is
+    deferred and applied at exit as ONE multi-tensor add instead of ~50 one-element kernel launches per step."""
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "pending", None)
+        _tls.pending = []
+        return self
+
+    def __exit__(self, *exc):
+        pending, _tls.pending = _tls.pending, self.prev
+        if pending:
+            torch._foreach_add_(pending, 1)
+        return False
+
+
 def bn_act(y, bn, slope=1.0, res_pre=None, res_post=None):
     """Applies the nn.BatchNorm3d module `bn` (parameters/buffers only; its forward is never called)."""
     momentum = 0.1 if bn.momentum is None else bn.momentum
@@ -541,7 +561,11 @@ def bn_act(y, bn, slope=1.0, res_pre=None, res_post=None):
     z = _BnAct.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, float(slope),
                      res_pre, res_post)
     if bn.training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+        pending = getattr(_tls, "pending", None)
+        if pending is not None:
+            pending.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked.add_(1)
     return z
 
 
