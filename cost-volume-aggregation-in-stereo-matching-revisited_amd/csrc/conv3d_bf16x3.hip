@@ -271,16 +271,13 @@ __global__ __launch_bounds__(512) void conv3_bf16x3_kernel(X3Args a) {
         for (int tap9 = 0; tap9 < 9; ++tap9) {
           const int cur = tap9 & 1;
           if (tap9 < 8) load_frag(tap9 + 1, cur ^ 1);
+          // smallest terms first; the two column tiles alternate so consecutive MFMAs never chain on one accumulator
+          constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            // smallest terms first
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][0], fb[cur][t][2], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][2], fb[cur][t][0], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][1], fb[cur][t][1], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][0], fb[cur][t][1], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][1], fb[cur][t][0], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][0], fb[cur][t][0], acc[t], 0, 0, 0);
-          }
+          for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][PA[q]], fb[cur][t][PB[q]], acc[t], 0, 0, 0);
           if (tap9 < 8) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) {
