@@ -9,10 +9,17 @@ import torch.nn.functional as F
 
 
 def model_loss(disp_ests, disp_gt, mask):
-    """reference loss.py:6-14: 1.8*SmoothL1(est0[mask]) + 2.1*SmoothL1(est1[mask])"""
+    """reference loss.py:6-14: 1.8*SmoothL1(est0[mask]) + 2.1*SmoothL1(est1[mask]), mean over the masked pixels.
+
+    Written as sum(mask * loss) / count(mask) instead of boolean indexing: same value and gradient (0/0 = NaN for an
+    empty mask, like the mean of an empty selection), but no `nonzero` -- boolean indexing synchronises the host with
+    the GPU in the middle of the training step, and everything after it is launched into an empty queue."""
     weights = [1.8, 2.1]
     assert len(weights) == len(disp_ests)
-    return sum(w * F.smooth_l1_loss(est[mask], disp_gt[mask], reduction="mean") for est, w in zip(disp_ests, weights))
+    m = mask.to(disp_gt.dtype)
+    count = m.sum()
+    return sum(w * (F.smooth_l1_loss(est, disp_gt, reduction="none") * m).sum() / count
+               for est, w in zip(disp_ests, weights))
 
 
 def _focal_level(est, gt, maxdisp, focal_coefficient, sparse):
