@@ -26,7 +26,15 @@ def _ptr(t: Optional[torch.Tensor]):
     return _vp(t.data_ptr()) if t is not None else None
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """torch's CURRENT stream on the current device as a hipStream_t (every launch goes there).  The raw C accessors
+    cost ~0.3 us against ~9 us for torch.cuda.current_stream() -- there are ~1000 launches per training step."""
+    if _raw_stream is not None and _raw_device is not None:
+        return _vp(_raw_stream(_raw_device()))
     return _vp(torch.cuda.current_stream().cuda_stream)
 
 
