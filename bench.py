@@ -87,6 +87,11 @@ def eval_step(m, fL, fR, guid):
 
 
 PEAK_BF16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
+PEAK_HBM_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+# algorithmic work of the eval forward at 544x960 / D=192 (G variant), fp32
+PATH_FWD_GFLOP, PATH_FWD_GB = 822.0, 10.71
+# ... and its fwd+bwd convention: 3 x (forward + training heads: 3 x 89.3 GFLOP, 0.87 Gelem)
+PATH_FB_GFLOP, PATH_FB_GB = 3 * (822.0 + 3 * 89.3), 3 * (2676.7 + 870.0) * 4e-3
 
 
 def kernel_roofline(device):
@@ -142,6 +147,11 @@ def kernel_roofline(device):
                           "wgrad3_bf16x3", PEAK_BF16_MFMA_TFLOPS / 6.0, run_wgrad(True)))
         cases.append(("wgrad3_kernel<S1> (+reduce) (dW of 3x3x3 32->32 @1/4 res, fp32 MFMA)", "wgrad3",
                       PEAK_FP32_MFMA_TFLOPS, run_wgrad(False)))
+        # the cost-volume builder itself is bandwidth bound: 4*(2*320*hw + 40*V4) algorithmic bytes per launch
+        fl, fr = torch.randn(1, 320, h, w, device=device), torch.randn(1, 320, h, w, device=device)
+        gwc_bytes = 4.0 * (2 * 320 * h * w + 40 * d * h * w)
+        cases.append(("gwc_fwd_kernel<8> (build_gwc_volume, 40 groups x %d disparities @1/4 res)" % d, None, None,
+                      lambda: ops.gwc_volume(fl, fr, d, 40)))
         for name, key, peak, fn in cases:
             for _ in range(2):
                 fn()
@@ -154,6 +164,12 @@ def kernel_roofline(device):
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / reps
+            if peak is None:   # HBM-bound entry
+                gbs = gwc_bytes / (ms * 1e-3) / 1e9
+                out[name] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                             "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "ms_per_launch": round(ms, 4),
+                             "algorithmic_bytes": gwc_bytes, "pmc_key": None}
+                continue
             tf = flops / (ms * 1e-3) / 1e12
             out[name] = {"bound": "mfma", "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(tf / peak, 4), "traffic": None, "ms_per_launch": round(ms, 4),
@@ -298,6 +314,15 @@ def main():
                     roof[n]["algorithmic_bytes"] = pmc[key]["algorithmic_bytes"]
         except (OSError, KeyError, ValueError):
             pass
+        if not args.shape:
+            # whole path against the two rooflines of SURVEY.md 8(d) (algorithmic bytes / FLOP per cost volume)
+            ms = dt / args.steps * 1e3 / args.batch
+            gflop, gb = (PATH_FWD_GFLOP, PATH_FWD_GB) if args.mode == "fwd" else (PATH_FB_GFLOP, PATH_FB_GB)
+            line["path_roofline"] = {
+                "algorithmic_gflop": round(gflop, 1), "algorithmic_gb": round(gb, 2),
+                "hbm_ms": round(gb / PEAK_HBM_GBS * 1e3, 3), "hbm_frac": round(gb / PEAK_HBM_GBS * 1e3 / ms, 4),
+                "fp32_mfma_ms": round(gflop / PEAK_FP32_MFMA_TFLOPS, 3),
+                "fp32_mfma_frac": round(gflop / PEAK_FP32_MFMA_TFLOPS / ms, 4)}
         if names:
             line["roofline"] = dict(roof[names[0]], kernel=names[0])
             line["roofline_other"] = {n: roof[n] for n in names[1:]}
