@@ -282,6 +282,102 @@ __global__ __launch_bounds__(256) void avgpool3d_bwd_kernel(const float* __restr
   }
 }
 
+// LDS-tiled forward for aligned inputs (Wi % 4 == 0): a workgroup produces an 8 x 32 (h x w) tile of one (channel, output
+// depth) plane from the 3 x 17 x 65 fine samples under it, staged once with 16-byte loads; same summation order as the
+// direct kernel above (bitwise identical results).
+__global__ __launch_bounds__(256) void avgpool3d_fwd_tiled_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                  int Di, int Hi, int Wi, int Do, int Ho, int Wo) {
+  constexpr int TH = 8, TW = 32, FH = 2 * TH + 1, PW = 2 * TW + 2;   // LDS column j = w' - (2*ow0 - 1), 65 used
+  __shared__ __attribute__((aligned(16))) float tile[3 * FH * PW];
+  const int tid = threadIdx.x, ow0 = blockIdx.x * TW, oh0 = blockIdx.y * TH;
+  const int od = blockIdx.z % Do;
+  const long nc = blockIdx.z / Do;
+  const long plane = (long)Di * Hi * Wi;
+  const __amdgpu_buffer_rsrc_t xr = dca_rsrc(x + nc * plane, plane * 4);
+  constexpr int NQ = 3 * FH * 16, KQ = (NQ + 255) / 256;   // 816 quads -> 4 per thread
+  float4 rq[KQ];
+#pragma unroll
+  for (int k = 0; k < KQ; ++k) {
+    const int it = tid + 256 * k, q = it & 15, row = it >> 4, a = row / FH, b = row - a * FH;
+    const int d = 2 * od - 1 + a, h = 2 * oh0 - 1 + b, w = 2 * ow0 + 4 * q;
+    const int ok = (int)(it < NQ) & (int)((unsigned)d < (unsigned)Di) & (int)((unsigned)h < (unsigned)Hi) & (int)(w < Wi);
+    rq[k] = dca_bload4(xr, ((d * Hi + h) * Wi + w) * 4, ok);
+  }
+  float redge = 0.f;
+  {
+    const int a = tid / FH, b = tid - a * FH;   // 3*FH = 51 left-edge samples (w' = 2*ow0 - 1)
+    const int d = 2 * od - 1 + a, h = 2 * oh0 - 1 + b, w = 2 * ow0 - 1;
+    const int ok = (int)(tid < 3 * FH) & (int)((unsigned)d < (unsigned)Di) & (int)((unsigned)h < (unsigned)Hi) &
+                   (int)((unsigned)w < (unsigned)Wi);
+    redge = dca_bload1(xr, ((d * Hi + h) * Wi + w) * 4, ok);
+  }
+#pragma unroll
+  for (int k = 0; k < KQ; ++k) {
+    const int it = tid + 256 * k;
+    if (it < NQ) {
+      float* p = tile + (it >> 4) * PW + 1 + 4 * (it & 15);
+      p[0] = rq[k].x; p[1] = rq[k].y; p[2] = rq[k].z; p[3] = rq[k].w;
+    }
+  }
+  if (tid < 3 * FH) tile[tid * PW] = redge;
+  __syncthreads();
+  const int hl = tid >> 5, wl = tid & 31, oh = oh0 + hl, ow = ow0 + wl;
+  if (oh >= Ho || ow >= Wo) return;
+  float s = 0.f;
+#pragma unroll
+  for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const float* row = tile + (kd * FH + 2 * hl + kh) * PW + 2 * wl;   // row[0..2] = fine w' = 2ow-1 .. 2ow+1
+      const float2 lo = *(const float2*)row;
+      s += lo.x;
+      s += lo.y;
+      s += row[2];
+    }
+  y[((nc * Do + od) * Ho + oh) * (long)Wo + ow] = s * (1.0f / 27.0f);
+}
+
+// Backward with 16-byte stores for aligned outputs (Wi % 4 == 0): a thread produces 4 consecutive fine w of one row
+// from the <= 2 x 2 x 3 coarse gradients above them; per-element summation order as in the scalar kernel.
+__global__ __launch_bounds__(256) void avgpool3d_bwd_vec_kernel(const float* __restrict__ gy, float* __restrict__ gx,
+                                                                int Di, int Hi, int Wi, int Do, int Ho, int Wo) {
+  const long row = blockIdx.x;
+  const int d = (int)(row % Di);
+  const long nc = row / Di;
+  const long plane = (long)Do * Ho * Wo;
+  const __amdgpu_buffer_rsrc_t gr = dca_rsrc(gy + nc * plane, plane * 4);
+  const int WQ = Wi >> 2, HQ = Hi * WQ, end = min(HQ, ((int)blockIdx.y + 1) * 1024);
+  const int d0 = d >> 1, dn = d & 1;
+  for (int i = blockIdx.y * 1024 + threadIdx.x; i < end; i += 256) {
+    const int h = i / WQ, t = i - h * WQ, h0 = h >> 1, hn = h & 1, c0 = 2 * t;   // fine w = 4t .. 4t+3, coarse c0 .. c0+2
+    float g[2][2][3];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int od = d0 + a, oh = h0 + b, ow = c0 + c;
+          const int ok = (a <= dn) & (b <= hn) & (int)(od < Do) & (int)(oh < Ho) & (int)(ow < Wo);
+          g[a][b][c] = dca_bload1(gr, ((od * Ho + oh) * Wo + ow) * 4, ok);
+        }
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {   // fine w = 4t + e: coarse {w >> 1, (w + 1) >> 1} = c0 + {e >> 1, (e + 1) >> 1}
+      float s = 0.f;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          s += g[a][b][e >> 1];
+          s += (e & 1) ? g[a][b][(e + 1) >> 1] : 0.f;
+        }
+      o[e] = s * (1.0f / 27.0f);
+    }
+    *(float4*)(gx + (row * Hi + h) * (long)Wi + 4 * t) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 // ------------------------------------------------------------------------------------ trilinear
 // align_corners=False, integer scale s: src = (dst+0.5)/s - 0.5 clamped at 0 (ATen area_pixel_compute_source_index)
 __device__ __forceinline__ void lin_src(int o, float rs, int n, int& i0, int& i1, float& l0, float& l1) {
@@ -446,6 +542,67 @@ __global__ __launch_bounds__(256) void trilinear_up2_bwd_kernel(const float* __r
   if (wok) gx[((nc * Di + d) * Hi + h) * Wi + w] = acc;
 }
 
+// LDS-tiled form for aligned inputs: a workgroup produces an 8 x 32 (h x w) coarse tile of one (channel, depth) plane
+// from the 4 x 18 x 66 fine samples it depends on, staged once with 16-byte loads (the direct form above re-reads each
+// fine sample ~8 times through L1 with 48 load instructions per output).  Same arithmetic, same summation order.
+__global__ __launch_bounds__(256) void trilinear_up2_bwd_tiled_kernel(const float* __restrict__ gy, float* __restrict__ gx,
+                                                                      int Di, int Hi, int Wi) {
+  constexpr int TH = 8, TW = 32, FH = 2 * TH + 2, FW = 2 * TW + 2, PW = FW + 2;   // LDS row: j = w' - (2*w0 - 1)
+  __shared__ __attribute__((aligned(16))) float tile[4 * FH * PW];
+  const int tid = threadIdx.x, w0 = blockIdx.x * TW, h0 = blockIdx.y * TH;
+  const int d = blockIdx.z % Di;
+  const long nc = blockIdx.z / Di;
+  const int Do = 2 * Di, Ho = 2 * Hi, Wo = 2 * Wi;
+  const long plane = (long)Do * Ho * Wo;
+  const __amdgpu_buffer_rsrc_t gr = dca_rsrc(gy + nc * plane, plane * 4);
+  // interior: 4 * FH rows x 16 quads (fine w' = 2*w0 + 4q .. +3); edges: two scalars per row (2*w0 - 1, 2*w0 + 64)
+  constexpr int NQ = 4 * FH * 16, KQ = (NQ + 255) / 256;   // 1152 quads -> 5 per thread, all loads issued up front
+  float4 rq[KQ];
+#pragma unroll
+  for (int k = 0; k < KQ; ++k) {
+    const int it = tid + 256 * k, q = it & 15, row = it >> 4, a = row / FH, b = row - a * FH;
+    const int od = 2 * d - 1 + a, oh = 2 * h0 - 1 + b, ow = 2 * w0 + 4 * q;
+    const int ok = (int)(it < NQ) & (int)((unsigned)od < (unsigned)Do) & (int)((unsigned)oh < (unsigned)Ho) &
+                   (int)(ow < Wo);  // Wo % 4 == 0: a quad is inside or outside as a whole
+    rq[k] = dca_bload4(gr, ((od * Ho + oh) * Wo + ow) * 4, ok);
+  }
+  float redge = 0.f;
+  {
+    const int side = tid & 1, row = tid >> 1, a = row / FH, b = row - a * FH;   // 4*FH*2 = 144 edge samples
+    const int od = 2 * d - 1 + a, oh = 2 * h0 - 1 + b, ow = side ? 2 * w0 + 2 * TW : 2 * w0 - 1;
+    const int ok = (int)(tid < 4 * FH * 2) & (int)((unsigned)od < (unsigned)Do) & (int)((unsigned)oh < (unsigned)Ho) &
+                   (int)((unsigned)ow < (unsigned)Wo);
+    redge = dca_bload1(gr, ((od * Ho + oh) * Wo + ow) * 4, ok);
+  }
+#pragma unroll
+  for (int k = 0; k < KQ; ++k) {
+    const int it = tid + 256 * k;
+    if (it < NQ) {
+      float* p = tile + (it >> 4) * PW + 1 + 4 * (it & 15);
+      p[0] = rq[k].x; p[1] = rq[k].y; p[2] = rq[k].z; p[3] = rq[k].w;
+    }
+  }
+  if (tid < 4 * FH * 2) tile[(tid >> 1) * PW + ((tid & 1) ? FW - 1 : 0)] = redge;
+  __syncthreads();
+  const int hl = tid >> 5, wl = tid & 31, h = h0 + hl, w = w0 + wl;
+  if (h >= Hi || w >= Wi) return;
+  float wd[4], wh[4], ww[4];
+  up2_bwd_w(d, Di, wd); up2_bwd_w(h, Hi, wh); up2_bwd_w(w, Wi, ww);
+  float acc = 0.f;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const float* row = tile + (a * FH + 2 * hl + b) * PW + 2 * wl;   // row[0..3] = fine w' = 2w-1 .. 2w+2
+      const float2 lo = *(const float2*)row, hi = *(const float2*)(row + 2);
+      float r = ww[1] * lo.y + ww[2] * hi.x;
+      r += ww[0] * lo.x;
+      r += ww[3] * hi.y;
+      acc += wd[a] * wh[b] * r;
+    }
+  gx[((nc * Di + d) * Hi + h) * Wi + w] = acc;
+}
+
 static int ew_grid(long total) {
   long g = (total + 255) / 256;
   return (int)(g < 8192 ? (g > 0 ? g : 1) : 8192);
@@ -517,6 +674,11 @@ extern "C" int dca_avgpool3d_fwd(const float* x, float* y, long NC, int Di, int 
   DCA_REQUIRE(x && y && NC > 0 && Di > 0 && Hi > 0 && Wi > 0);
   const int Do = (Di + 1) / 2, Ho = (Hi + 1) / 2, Wo = (Wi + 1) / 2;  // floor((i+2-3)/2)+1
   DCA_REQUIRE((long)Di * Hi * Wi * 4 < 0x7ffffff0L && NC * Do < 0x7fffffffL);  // 32-bit offsets inside one channel
+  if (Wi % 4 == 0 && (((uintptr_t)x) & 15) == 0 && NC * Do <= 65535 && cdiv(Ho, 8) <= 65535) {
+    hipLaunchKernelGGL(avgpool3d_fwd_tiled_kernel, dim3(cdiv(Wo, 32), cdiv(Ho, 8), (unsigned)(NC * Do)), dim3(256), 0, stream,
+                       x, y, Di, Hi, Wi, Do, Ho, Wo);
+    return dca_launch_status();
+  }
   hipLaunchKernelGGL(avgpool3d_fwd_kernel, dim3((unsigned)(NC * Do), cdiv((long)Ho * Wo, 1024)), dim3(256), 0, stream, x,
                      y, Di, Hi, Wi, Do, Ho, Wo);
   return dca_launch_status();
@@ -526,6 +688,11 @@ extern "C" int dca_avgpool3d_bwd(const float* gy, float* gx, long NC, int Di, in
   DCA_REQUIRE(gy && gx && NC > 0 && Di > 0 && Hi > 0 && Wi > 0);
   const int Do = (Di + 1) / 2, Ho = (Hi + 1) / 2, Wo = (Wi + 1) / 2;
   DCA_REQUIRE((long)Di * Hi * Wi * 4 < 0x7ffffff0L && NC * Di < 0x7fffffffL);
+  if (Wi % 4 == 0 && (((uintptr_t)gx) & 15) == 0) {
+    hipLaunchKernelGGL(avgpool3d_bwd_vec_kernel, dim3((unsigned)(NC * Di), cdiv((long)Hi * (Wi / 4), 1024)), dim3(256), 0,
+                       stream, gy, gx, Di, Hi, Wi, Do, Ho, Wo);
+    return dca_launch_status();
+  }
   hipLaunchKernelGGL(avgpool3d_bwd_kernel, dim3((unsigned)(NC * Di), cdiv((long)Hi * Wi, 1024)), dim3(256), 0, stream, gy,
                      gx, Di, Hi, Wi, Do, Ho, Wo);
   return dca_launch_status();
@@ -547,6 +714,12 @@ extern "C" int dca_trilinear_fwd(const float* x, float* y, long NC, int Di, int 
 extern "C" int dca_trilinear_bwd(const float* gy, float* gx, long NC, int Di, int Hi, int Wi, int scale,
                                  hipStream_t stream) {
   DCA_REQUIRE(gy && gx && NC > 0 && Di > 0 && Hi > 0 && Wi > 0 && scale >= 1);
+  if (scale == 2 && cdiv(Hi, 8) <= 65535 && NC * Di <= 65535 && 32L * Di * Hi * Wi < 0x7ffffff0L && Wi % 2 == 0 &&
+      (((uintptr_t)gy & 15) == 0)) {
+    hipLaunchKernelGGL(trilinear_up2_bwd_tiled_kernel, dim3(cdiv(Wi, 32), cdiv(Hi, 8), (unsigned)(NC * Di)), dim3(256), 0,
+                       stream, gy, gx, Di, Hi, Wi);
+    return dca_launch_status();
+  }
   if (scale == 2 && Hi <= 65535 && NC * Di <= 65535 && 32L * Di * Hi * Wi < 0x7ffffff0L && (((uintptr_t)gy & 7) == 0)) {
     hipLaunchKernelGGL(trilinear_up2_bwd_kernel, dim3(cdiv(Wi, 256), Hi, (unsigned)(NC * Di)), dim3(256), 0, stream, gy, gx,
                        Di, Hi, Wi);

@@ -359,7 +359,7 @@ def test_convbn_fused_inference_matches_unfused():
 
 
 # ------------------------------------------------------------------------------------- pool / interp
-@pytest.mark.parametrize("dims", [(4, 6, 10), (5, 7, 9), (8, 8, 16)])
+@pytest.mark.parametrize("dims", [(4, 6, 10), (5, 7, 9), (8, 8, 16), (6, 18, 68), (5, 17, 72)])
 def test_avgpool(dims):
     _, ops = _mods()
     x = seeded_tensor("ap.x", (2, 3) + dims)
@@ -373,7 +373,8 @@ def test_avgpool(dims):
     close(y, yr, 1e-6); close(gx, gxr, 1e-6)
 
 
-@pytest.mark.parametrize("scale,dims", [(2, (2, 3, 5)), (2, (4, 6, 10)), (8, (2, 2, 3)), (8, (1, 3, 4))])
+@pytest.mark.parametrize("scale,dims", [(2, (2, 3, 5)), (2, (4, 6, 10)), (2, (3, 9, 34)), (2, (5, 17, 66)), (8, (2, 2, 3)),
+                                        (8, (1, 3, 4))])
 def test_trilinear(scale, dims):
     _, ops = _mods()
     x = seeded_tensor("tl.x", (2, 3) + dims)
