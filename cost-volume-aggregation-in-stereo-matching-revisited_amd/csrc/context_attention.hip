@@ -202,9 +202,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 }
 
 // backward, two phases inside one workgroup (32 pixels x one head), no atomics:
-//  phase 1, thread = (pixel, query i): softmax statistics (m, 1/l), D_i = sum_j p_ij dP_ij, and dq_i;
-//           (m, 1/l, D) go to LDS next to the staged q / dout tiles.
-//  phase 2, thread = (pixel, key j):   dk_j = sum_i dS_ij q_i / sqrt(8), dv_j = sum_i p_ij dout_i in registers.
+//  phase 1, thread = (pixel, queries i = qg + 8t, t < QPT): softmax statistics (m, 1/l), D_i = sum_j p_ij dP_ij and
+//           dq_i; (m, 1/l, D) go to LDS next to the staged q / dout tiles.
+//  phase 2, thread = (pixel, keys j = qg + 8t):  dk_j = sum_i dS_ij q_i / sqrt(8), dv_j = sum_i p_ij dout_i in registers.
+// A thread's QPT queries (keys) share every k/v (q/dout) value it reads from LDS, which divides the LDS traffic by QPT
+// and gives QPT independent dependency chains (the workgroup's 107 KB of LDS allow only one wave per SIMD).
+template <int QPT>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                        const float* __restrict__ v, const float* __restrict__ dout,
                                                        float* __restrict__ dq, float* __restrict__ dk,
@@ -231,81 +234,130 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     gs[it] = ok ? dout[g] : 0.f;
   }
   __syncthreads();
-  for (int i = qg; i < n; i += 8) {
-    float qv[8], go[8], dqv[8];
+  {
+    float qv[QPT][8], go[QPT][8], dqv[QPT][8], m[QPT], l[QPT], dnum[QPT];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      qv[c] = qs[(c * n + i) * 32 + pl];
-      go[c] = gs[(c * n + i) * 32 + pl];
-      dqv[c] = 0.f;
-    }
-    float m = -INFINITY, l = 0.f, dnum = 0.f;
-    for (int j = 0; j < n; ++j) {
-      float s = 0.f, dp = 0.f;
+    for (int t = 0; t < QPT; ++t) {
+      const int i = min(qg + 8 * t, n - 1);
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        s += qv[c] * ks[(c * n + j) * 32 + pl];
-        dp += go[c] * vs[(c * n + j) * 32 + pl];
+        qv[t][c] = qs[(c * n + i) * 32 + pl];
+        go[t][c] = gs[(c * n + i) * 32 + pl];
+        dqv[t][c] = 0.f;
       }
-      const float mn = fmaxf(m, s);
-      const float corr = expf(m - mn), p = expf(s - mn);
-      l = l * corr + p;
-      dnum = dnum * corr + p * dp;
-      m = mn;
+      m[t] = -INFINITY; l[t] = 0.f; dnum[t] = 0.f;
     }
-    const float inv = 1.f / l, Dsum = dnum * inv;
-    st[(0 * n + i) * 32 + pl] = m;
-    st[(1 * n + i) * 32 + pl] = inv;
-    st[(2 * n + i) * 32 + pl] = Dsum;
     for (int j = 0; j < n; ++j) {
-      float s = 0.f, dp = 0.f, kj[8];
+      float kj[8], vj[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         kj[c] = ks[(c * n + j) * 32 + pl];
-        s += qv[c] * kj[c];
-        dp += go[c] * vs[(c * n + j) * 32 + pl];
+        vj[c] = vs[(c * n + j) * 32 + pl];
       }
-      const float ds = expf(s - m) * inv * (dp - Dsum);
 #pragma unroll
-      for (int c = 0; c < 8; ++c) dqv[c] += ds * kj[c];
+      for (int t = 0; t < QPT; ++t) {
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          s += qv[t][c] * kj[c];
+          dp += go[t][c] * vj[c];
+        }
+        const float mn = fmaxf(m[t], s);
+        const float corr = expf(m[t] - mn), p = expf(s - mn);
+        l[t] = l[t] * corr + p;
+        dnum[t] = dnum[t] * corr + p * dp;
+        m[t] = mn;
+      }
     }
-    if (pix < HW) {
+    float inv[QPT], Dsum[QPT];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) dq[hb + ((long)c * n + i) * HW + pix] = dqv[c] * scale;
+    for (int t = 0; t < QPT; ++t) {
+      const int i = qg + 8 * t;
+      inv[t] = 1.f / l[t];
+      Dsum[t] = dnum[t] * inv[t];
+      if (i < n) {
+        st[(0 * n + i) * 32 + pl] = m[t];
+        st[(1 * n + i) * 32 + pl] = inv[t];
+        st[(2 * n + i) * 32 + pl] = Dsum[t];
+      }
+    }
+    for (int j = 0; j < n; ++j) {
+      float kj[8], vj[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        kj[c] = ks[(c * n + j) * 32 + pl];
+        vj[c] = vs[(c * n + j) * 32 + pl];
+      }
+#pragma unroll
+      for (int t = 0; t < QPT; ++t) {
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          s += qv[t][c] * kj[c];
+          dp += go[t][c] * vj[c];
+        }
+        const float ds = expf(s - m[t]) * inv[t] * (dp - Dsum[t]);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) dqv[t][c] += ds * kj[c];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < QPT; ++t) {
+      const int i = qg + 8 * t;
+      if (i < n && pix < HW) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) dq[hb + ((long)c * n + i) * HW + pix] = dqv[t][c] * scale;
+      }
     }
   }
   __syncthreads();
-  for (int j = qg; j < n; j += 8) {
-    float kj[8], vj[8], dkj[8], dvj[8];
+  {
+    float kj[QPT][8], vj[QPT][8], dkj[QPT][8], dvj[QPT][8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      kj[c] = ks[(c * n + j) * 32 + pl];
-      vj[c] = vs[(c * n + j) * 32 + pl];
-      dkj[c] = 0.f;
-      dvj[c] = 0.f;
+    for (int t = 0; t < QPT; ++t) {
+      const int j = min(qg + 8 * t, n - 1);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        kj[t][c] = ks[(c * n + j) * 32 + pl];
+        vj[t][c] = vs[(c * n + j) * 32 + pl];
+        dkj[t][c] = 0.f;
+        dvj[t][c] = 0.f;
+      }
     }
     for (int i = 0; i < n; ++i) {
-      float qv[8], go[8], s = 0.f, dp = 0.f;
+      float qv[8], go[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         qv[c] = qs[(c * n + i) * 32 + pl];
         go[c] = gs[(c * n + i) * 32 + pl];
-        s += qv[c] * kj[c];
-        dp += go[c] * vj[c];
       }
-      const float p = expf(s - st[(0 * n + i) * 32 + pl]) * st[(1 * n + i) * 32 + pl];
-      const float ds = p * (dp - st[(2 * n + i) * 32 + pl]);
+      const float mi = st[(0 * n + i) * 32 + pl], li = st[(1 * n + i) * 32 + pl], Di = st[(2 * n + i) * 32 + pl];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        dkj[c] += ds * qv[c];   // qv already carries 1/sqrt(8)
-        dvj[c] += p * go[c];
+      for (int t = 0; t < QPT; ++t) {
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          s += qv[c] * kj[t][c];
+          dp += go[c] * vj[t][c];
+        }
+        const float p = expf(s - mi) * li;
+        const float ds = p * (dp - Di);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          dkj[t][c] += ds * qv[c];   // qv already carries 1/sqrt(8)
+          dvj[t][c] += p * go[c];
+        }
       }
     }
-    if (pix < HW) {
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        dk[hb + ((long)c * n + j) * HW + pix] = dkj[c];
-        dv[hb + ((long)c * n + j) * HW + pix] = dvj[c];
+    for (int t = 0; t < QPT; ++t) {
+      const int j = qg + 8 * t;
+      if (j < n && pix < HW) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          dk[hb + ((long)c * n + j) * HW + pix] = dkj[t][c];
+          dv[hb + ((long)c * n + j) * HW + pix] = dvj[t][c];
+        }
       }
     }
   }
@@ -373,12 +425,21 @@ extern "C" int dca_disp_attention_bwd(const float* q, const float* k, const floa
   DCA_REQUIRE(q && k && v && dout && dq && dk && dv && B > 0 && C > 0 && C % 8 == 0 && n > 0 && n <= 32 && HW > 0);
   DCA_REQUIRE(C / 8 <= 65535 && B <= 65535);
   const size_t lds = (size_t)(4 * 8 + 3) * n * 32 * 4;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
-    if (e != hipSuccess) return (int)e;
-  }
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(cdiv(HW, 32), C / 8, B), dim3(256), lds, stream, q, k, v, dout, dq, dk, dv,
-                     C, n, HW);
+  const dim3 grid(cdiv(HW, 32), C / 8, B);
+  const int qpt = (n + 7) / 8;
+#define LAUNCH(Q)                                                                                                      \
+  do {                                                                                                                 \
+    if (lds > 64 * 1024) {                                                                                             \
+      hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel<Q>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                         (int)lds);                                                                    \
+      if (e != hipSuccess) return (int)e;                                                                              \
+    }                                                                                                                  \
+    hipLaunchKernelGGL(attn_bwd_kernel<Q>, grid, dim3(256), lds, stream, q, k, v, dout, dq, dk, dv, C, n, HW);         \
+  } while (0)
+  if (qpt == 1) LAUNCH(1);
+  else if (qpt == 2) LAUNCH(2);
+  else if (qpt == 3) LAUNCH(3);
+  else LAUNCH(4);
+#undef LAUNCH
   return dca_launch_status();
 }
