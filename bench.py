@@ -65,6 +65,11 @@ def make_inputs(batch, rank, device, h4=H_IMG // 4, w4=W_IMG // 4):
     return fL, fR, guid, gt
 
 
+def _conv_x3():
+    from dcanet_amd import ops
+    return ops.CONV_X3
+
+
 def train_step(m, fL, fR, guid, gt, bucket, opt):
     from dcanet_amd.models.loss import focal_loss, model_loss
     bucket.zero()
@@ -295,7 +300,13 @@ def main():
             "value": round(volumes / dt, 4), "unit": "cost-volumes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "dtype_note": ("fp32 tensors and fp32 accumulation everywhere; the 3x3x3 stride-1 convolutions and their weight "
+                           "gradients evaluate each fp32 product exactly-split into three bf16 terms (six bf16 MFMA products, "
+                           "dropped terms <= 2^-23): measured against fp64 as accurate as the fp32 MFMA kernels "
+                           "(tests/test_gpu_parity.py::test_conv3d_bf16x3_is_fp32_grade); DCA_CONV=fp32 selects the fp32 MFMA "
+                           "kernels") if _conv_x3() else "fp32 MFMA kernels everywhere (DCA_CONV=fp32)",
+            "data": "synthetic",
             "config": {"workload": "gwcnet_dca_g (GwcNet-G + 3 DCA blocks) hot path from 1/4-res features, "
                                    f"{H_IMG}x{W_IMG} D={MAXDISP}, " + ("train step: fwd(all heads)+focal/model loss+bwd+allreduce+Adam"
                                                         if args.mode == "fwdbwd" else "eval forward"),
