@@ -91,6 +91,7 @@ def eval_step(m, fL, fR, guid):
         return m.prop(guid, r["pred4_q"])
 
 
+
 PEAK_BF16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
 PEAK_HBM_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 # algorithmic work of the eval forward at 544x960 / D=192 (G variant), fp32
@@ -271,6 +272,13 @@ def main():
         else:
             step = lambda: eval_step(m, fL, fR, guid)
 
+    import contextlib
+    frozen = contextlib.ExitStack()
+    if args.mode == "fwd":
+        # inference: parameters are frozen for the whole run, so weight re-layouts and BatchNorm folds are computed
+        # once (during warm-up) instead of per call -- ordinary inference-engine weight pre-packing
+        from dcanet_amd import ops as _ops
+        frozen.enter_context(_ops.frozen_weights())
     for _ in range(args.warmup):
         step()
 
@@ -287,6 +295,7 @@ def main():
     t_enq = time.perf_counter() - t0   # host time to enqueue the steps (== dt when the host, not the GPU, is the limit)
     fence()
     dt = time.perf_counter() - t0
+    frozen.close()
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -311,7 +320,8 @@ def main():
                                    f"{H_IMG}x{W_IMG} D={MAXDISP}, " + ("train step: fwd(all heads)+focal/model loss+bwd+allreduce+Adam"
                                                         if args.mode == "fwdbwd" else "eval forward"),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "mode": args.mode, "hipgraph": bool(args.graph)},
+                       "mode": args.mode, "hipgraph": bool(args.graph),
+                       "weight_prepack": "once (ops.frozen_weights)" if args.mode == "fwd" else "every step (weights change)"},
         }
         roof = kernel_roofline(device) if not args.shape else {}
         names = list(roof)

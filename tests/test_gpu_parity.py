@@ -276,6 +276,29 @@ def test_conv3d_winograd_path(case, monkeypatch):
     close(y, yr, 1e-5, "fwd"); close(gx, gxr, 1e-5, "dx"); close_l2(gw, gwr, 1e-5, "dw")
 
 
+def test_frozen_weights_cache_is_exact_and_scoped():
+    """ops.frozen_weights(): cached weight re-layouts / BN folds give bit-identical results, are reused inside the
+    context, and are dropped (weights may change again) outside it"""
+    _, ops = _mods()
+    import torch.nn as nn
+    conv = nn.Conv3d(32, 32, 3, 1, 1, bias=False).to(DEV); bn = nn.BatchNorm3d(32).to(DEV).eval()
+    with torch.no_grad():
+        conv.weight.copy_(seeded_tensor("fw.w", conv.weight.shape).to(DEV) * 0.05)
+        bn.running_mean.copy_(seeded_tensor("fw.m", (32,)).to(DEV)); bn.running_var.copy_(seeded_tensor("fw.v", (32,)).abs().to(DEV) + 0.5)
+        x = seeded_tensor("fw.x", (1, 32, 4, 8, 16)).to(DEV)
+        y0 = ops.convbn3d(x, conv, bn, 0.0)
+        with ops.frozen_weights():
+            y1 = ops.convbn3d(x, conv, bn, 0.0)
+            n_cached = len(ops._tls.frozen)
+            y2 = ops.convbn3d(x, conv, bn, 0.0)
+            assert len(ops._tls.frozen) == n_cached and n_cached >= 2     # weight image + BN fold, reused
+        assert torch.equal(y0, y1) and torch.equal(y0, y2)
+        assert getattr(ops._tls, "frozen", None) is None
+        conv.weight.mul_(2.0)                                              # outside the context: picked up at once
+        y3 = ops.convbn3d(x, conv, bn, 0.0)
+        assert not torch.equal(y3, y0)
+
+
 def test_conv1x1_two_inputs():
     _, ops = _mods()
     dims, N = (4, 6, 12), 2
