@@ -201,6 +201,30 @@ def test_conv3d_bf16x3_path(case, monkeypatch):
     close(y, yr, 1e-5, "fwd"); close(gx, gxr, 1e-5, "dx"); close_l2(gw, gwr, 1e-5, "dw")
 
 
+def test_conv3d_bf16x3_random_shapes(monkeypatch):
+    """randomised shapes (tiny dims, channel counts off the 16/32 grid, W on and off the aligned path, batches) through
+    the bf16x3 forward / backward-data / weight-gradient kernels against fp64 (tools/x3_stress.py runs 60 of these)"""
+    import random
+    _, ops = _mods()
+    monkeypatch.setattr(ops, "CONV_X3", True)
+    rnd = random.Random(3)
+    g = torch.Generator().manual_seed(3)
+    for _ in range(16):
+        N = rnd.choice([1, 2, 3]); cin = rnd.choice([1, 3, 16, 17, 40, 64]); cout = rnd.choice([1, 2, 27, 33, 64])
+        D, H, W = rnd.randint(1, 7), rnd.randint(1, 12), rnd.choice([1, 3, 4, 8, 17, 20, 33])
+        x = torch.randn(N, cin, D, H, W, generator=g); w = torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.1
+        xg, wg = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_()
+        y = ops._Conv3d.apply(xg, None, wg, 1, False)
+        gy = torch.randn(y.shape, generator=g)
+        gx, gw = torch.autograd.grad((y * gy.to(DEV)).sum(), [xg, wg])
+        xd, wd = x.double().requires_grad_(), w.double().requires_grad_()
+        yr = F.conv3d(xd, wd, None, 1, 1)
+        gxr, gwr = torch.autograd.grad((yr * gy.double()).sum(), [xd, wd])
+        for got, ref, name in ((y, yr, "fwd"), (gx, gxr, "dx"), (gw, gwr, "dw")):
+            err = (got.detach().cpu().double() - ref.detach()).abs().max().item()
+            assert err <= 1e-5 * (ref.abs().max().item() + 1e-30), (name, (N, cin, cout, D, H, W), err)
+
+
 def test_conv3d_bf16x3_is_fp32_grade(monkeypatch):
     """against an fp64 convolution the split kernel must be as accurate as the fp32 MFMA kernel (it drops only
     partial products below 2^-23 relative), including for operands spanning many binades"""
