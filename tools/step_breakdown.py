@@ -11,7 +11,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "gwc_fwd" in r["Kernel_Name"]]
 # last pair of gwc_fwd launches with a whole step between them (kernel_roofline() launches gwc_fwd back to back at the end)
 pairs = [(a, b) for a, b in zip(idx[:-1], idx[1:]) if b - a > 100]
-a, b = pairs[-1]
+a, b = pairs[-2] if len(pairs) > 1 else pairs[-1]   # the last pair also spans the micro-benchmarks after the timed loop
 win = rows[a:b]
 tot, cnt = collections.Counter(), collections.Counter()
 for r in win:
