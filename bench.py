@@ -70,7 +70,8 @@ def _conv_x3():
     return ops.CONV_X3
 
 
-def train_step(m, fL, fR, guid, gt, bucket, opt):
+def train_local(m, fL, fR, guid, gt, bucket):
+    """this rank's part of the step: forward (all heads), losses, backward, gradients gathered into the flat bucket"""
     from dcanet_amd.models.loss import focal_loss, model_loss
     bucket.zero()
     fL.grad = fR.grad = None
@@ -80,7 +81,13 @@ def train_step(m, fL, fR, guid, gt, bucket, opt):
     loss = focal_loss([r["pred0"], r["pred_dca1"], r["pred_dca2"], r["pred1"], r["pred2"]], gt, MAXDISP, 5.0, False) \
         + model_loss([r["pred_dca3"], pred4], gt, mask)
     loss.backward()
-    bucket.all_reduce_mean()
+    bucket.gather()
+    return loss.detach()
+
+
+def train_step(m, fL, fR, guid, gt, bucket, opt):
+    loss = train_local(m, fL, fR, guid, gt, bucket)
+    bucket.reduce_flat()
     opt.step()
     return loss
 
@@ -233,7 +240,10 @@ def main():
     ap.add_argument("--mode", choices=["fwdbwd", "fwd"], default="fwdbwd")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=34)
-    ap.add_argument("--graph", action="store_true", help="fwd mode: replay the eval hot path as one hipGraph")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the eval hot path (fwd) / the whole training step (fwdbwd, dcanet_amd.graph."
+                         "GraphedTrainStep) as captured hipGraphs; off by default: at this shape the step is GPU bound "
+                         "and the replay measures the same as eager launches")
     ap.add_argument("--shape", default=None, help="HxWxD of a secondary workload (e.g. 384x1248x192 KITTI, "
                                                   "256x512x64 plumbing); default = BASELINE's 544x960x192")
     args = ap.parse_args()
@@ -253,13 +263,25 @@ def main():
 
     m = build_model(device)
     fL, fR, guid, gt = make_inputs(args.batch, rank, device)
+    train_graphed, graph_error = False, None
     if args.mode == "fwdbwd":
         m.train()
         fL.requires_grad_(); fR.requires_grad_()
         params = hot_params(m)
         bucket = FlatGradBucket(params)
-        opt = torch.optim.Adam(params, lr=1e-3, betas=(0.9, 0.999))
+        opt = torch.optim.Adam(params, lr=1e-3, betas=(0.9, 0.999), capturable=bool(args.graph))
         step = lambda: train_step(m, fL, fR, guid, gt, bucket, opt)
+        if args.graph:
+            # the whole step as hipGraph replays (dcanet_amd.graph.GraphedTrainStep); any capture problem -> eager
+            try:
+                from dcanet_amd.graph import GraphedTrainStep
+                step = GraphedTrainStep(lambda: train_local(m, fL, fR, guid, gt, bucket), opt.step,
+                                        bucket.reduce_flat if world > 1 else None)
+                train_graphed = True
+            except Exception as e:   # noqa: BLE001
+                graph_error = f"{type(e).__name__}: {e}"[:200]
+                torch.cuda.synchronize()
+                step = lambda: train_step(m, fL, fR, guid, gt, bucket, opt)
     else:
         m.eval()
         if args.graph:
@@ -320,7 +342,8 @@ def main():
                                    f"{H_IMG}x{W_IMG} D={MAXDISP}, " + ("train step: fwd(all heads)+focal/model loss+bwd+allreduce+Adam"
                                                         if args.mode == "fwdbwd" else "eval forward"),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "mode": args.mode, "hipgraph": bool(args.graph),
+                       "mode": args.mode, "hipgraph": bool(args.graph) if args.mode == "fwd" else train_graphed,
+                       **({"hipgraph_error": graph_error} if graph_error else {}),
                        "weight_prepack": "once (ops.frozen_weights)" if args.mode == "fwd" else "every step (weights change)"},
         }
         roof = kernel_roofline(device) if not args.shape else {}

@@ -1,4 +1,5 @@
-"""hipGraph capture of the eval-mode hot path (BASELINE config 5: "hipGraph-captured 3D hourglass").
+"""hipGraph capture of the eval-mode hot path (BASELINE config 5: "hipGraph-captured 3D hourglass") and of the whole
+training step.
 
 The forward is ~175 kernel launches through ctypes; at 544x960 the GPU is the bottleneck, but at small shapes
 (256x512, D=64) the step is host-bound.  All launches go to torch's current stream, every buffer comes from torch's
@@ -33,4 +34,46 @@ class GraphedHotPath:
             assert s.shape == t.shape, "graph was captured for a different shape"
             s.copy_(t)
         self.graph.replay()
+        return self.static_out
+
+
+class GraphedTrainStep:
+    """One training step as hipGraph replays: `local_step()` (zero grads, forward, losses, backward, gradient gather --
+    ~1000 launches through ctypes and the autograd engine) is captured into one graph and `optimizer_step()` into the
+    same graph (single process) or a second one (data parallel: the all-reduce stays an eager RCCL call between the two
+    replays).  Requirements, all met by this package: no host synchronisation inside the step (models/loss.py avoids
+    boolean indexing), static input tensors, an optimizer built with `capturable=True`, every launch on torch's current
+    stream, every buffer from torch's allocator.
+
+    Construct it under the stream the training loop runs on; `__call__()` replays one step and returns the (static)
+    value `local_step` returned."""
+
+    def __init__(self, local_step, optimizer_step, all_reduce=None, warmup: int = 3):
+        self.all_reduce = all_reduce
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                    # optimizer state, allocator pools, kernel attributes
+            for _ in range(warmup):
+                local_step()
+                if all_reduce is not None:
+                    all_reduce()
+                optimizer_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph_a = torch.cuda.CUDAGraph()
+        self.graph_b = None
+        with torch.cuda.graph(self.graph_a):
+            self.static_out = local_step()
+            if all_reduce is None:
+                optimizer_step()
+        if all_reduce is not None:
+            self.graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+                optimizer_step()
+
+    def __call__(self):
+        self.graph_a.replay()
+        if self.graph_b is not None:
+            self.all_reduce()
+            self.graph_b.replay()
         return self.static_out

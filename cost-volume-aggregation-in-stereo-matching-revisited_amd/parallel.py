@@ -66,11 +66,15 @@ class FlatGradBucket:
         for p, v in zip(self.params, self.views):
             p.grad = v
 
-    def all_reduce_mean(self):
-        self.gather()
+    def reduce_flat(self):
+        """the collective alone (the flat buffer must already hold this rank's gradients: see gather())"""
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.div_(dist.get_world_size())
+
+    def all_reduce_mean(self):
+        self.gather()
+        self.reduce_flat()
 
 
 def shard_batch(t: torch.Tensor, rank: int, world: int) -> torch.Tensor:

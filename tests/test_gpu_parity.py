@@ -726,3 +726,47 @@ def test_training_step_is_bitwise_reproducible():
         runs.append([r["pred4_q"].detach().clone(), r["pred_dca3"].detach().clone()] + [g.clone() for g in gr])
     for a, b in zip(*runs):
         assert torch.equal(a, b)
+
+
+def test_graphed_train_step_matches_eager():
+    """dcanet_amd.graph.GraphedTrainStep: the whole training step (forward, losses, backward, gradient gather, Adam with
+    capturable=True) replayed as one hipGraph gives the same parameters as the same steps launched eagerly"""
+    import copy
+    from dcanet_amd.graph import GraphedTrainStep
+    from dcanet_amd.models.gwcnet_dca_g import GwcNet
+    from dcanet_amd.models.loss import focal_loss, model_loss
+    from dcanet_amd.parallel import FlatGradBucket
+    torch.manual_seed(0)
+    base = load_seeded(GwcNet(32, use_concat_volume=False)).to(DEV).train()
+    fL, fR = gpu(seeded_tensor("gts.fL", (1, 320, 16, 32))), gpu(seeded_tensor("gts.fR", (1, 320, 16, 32)))
+    gt = (seeded_tensor("gts.gt", (1, 1, 64, 128)).abs() * 10 + 1).to(DEV)
+
+    def build(model):
+        mods = [model.dres0, model.dres1, model.cva1, model.cva2, model.cva3, model.classif0, model.classif1,
+                model.classif2, model.classif3]
+        params = [p for mm in mods for p in mm.parameters()]
+        bucket = FlatGradBucket(params)
+        opt = torch.optim.Adam(params, lr=1e-3, capturable=True)
+
+        def local():
+            bucket.zero()
+            r = model.hot_path(fL, fR)
+            up = torch.nn.functional.interpolate(r["pred4_q"], scale_factor=4, mode="bilinear") * 4
+            mask = (gt < 32) & (gt > 0)
+            loss = focal_loss([r["pred0"], r["pred_dca1"], r["pred_dca2"], r["pred1"], r["pred2"]], gt, 32, 5.0, False) \
+                + model_loss([r["pred_dca3"], up], gt, mask)
+            loss.backward()
+            bucket.gather()
+            return loss.detach()
+        return params, local, opt
+
+    m_e, m_g = copy.deepcopy(base), copy.deepcopy(base)
+    pe, local_e, opt_e = build(m_e)
+    for _ in range(3 + 2):                       # GraphedTrainStep runs 3 eager warm-up steps, then we replay twice
+        local_e(); opt_e.step()
+    pg, local_g, opt_g = build(m_g)
+    step = GraphedTrainStep(local_g, opt_g.step)
+    step(); step()
+    torch.cuda.synchronize()
+    worst = max(((a - b).abs().max() / (b.abs().max() + 1e-12)).item() for a, b in zip(pg, pe))
+    assert worst == 0.0, worst                   # same kernels, same order, no atomics: bitwise
