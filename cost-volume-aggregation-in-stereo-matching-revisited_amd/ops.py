@@ -575,7 +575,7 @@ class frozen_weights:
 def _memo(key, tensors, build):
     """build() once per (key, identity of `tensors`) inside a frozen_weights() context; plain build() otherwise"""
     cache = getattr(_tls, "frozen", None)
-    if cache is None or torch.cuda.is_current_stream_capturing():
+    if cache is None or (tensors and tensors[0].is_cuda and torch.cuda.is_current_stream_capturing()):
         return build()
     k = (key,) + tuple((id(t), t.data_ptr()) for t in tensors)
     hit = cache.get(k)

@@ -102,3 +102,32 @@ def test_losses_match_reference(golden=None):
     gd = torch.autograd.grad(ml, [d0, d1])
     assert torch.allclose(gd[0], torch.from_numpy(g["gd0"]), atol=1e-7, rtol=1e-4)
     assert torch.allclose(gd[1], torch.from_numpy(g["gd1"]), atol=1e-7, rtol=1e-4)
+
+
+def test_frozen_weights_and_batched_counters_host_logic():
+    """ops.frozen_weights(): memoised per source-tensor identity inside the context only; ops.batched_bn_counters():
+    deferred `num_batches_tracked += 1` applied once at exit (a module used twice counts twice)"""
+    import dcanet_amd  # noqa: F401
+    from dcanet_amd import ops
+    t, u, calls = torch.zeros(3), torch.zeros(3), []
+
+    def build():
+        calls.append(1)
+        return torch.ones(1)
+    with ops.frozen_weights():
+        a = ops._memo(("k", 1), (t,), build)
+        assert ops._memo(("k", 1), (t,), build) is a and len(calls) == 1          # reused
+        assert ops._memo(("k", 2), (t,), build) is not a and len(calls) == 2      # another layout of the same weight
+        assert ops._memo(("k", 1), (u,), build) is not a and len(calls) == 3      # another tensor
+        with ops.frozen_weights():                                                 # nested context: its own cache
+            ops._memo(("k", 1), (t,), build)
+            assert len(calls) == 4
+        assert ops._memo(("k", 1), (t,), build) is a and len(calls) == 4
+    ops._memo(("k", 1), (t,), build)
+    assert len(calls) == 5 and getattr(ops._tls, "frozen", None) is None           # outside: always rebuilt
+
+    n1, n2 = torch.zeros((), dtype=torch.long), torch.zeros((), dtype=torch.long)
+    with ops.batched_bn_counters():
+        ops._tls.pending += [n1, n1, n2]
+        assert n1.item() == 0
+    assert (n1.item(), n2.item()) == (2, 1) and getattr(ops._tls, "pending", None) is None
