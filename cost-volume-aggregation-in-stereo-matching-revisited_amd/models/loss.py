@@ -22,8 +22,9 @@ def model_loss(disp_ests, disp_gt, mask):
                for est, w in zip(disp_ests, weights))
 
 
-def _focal_level(est, gt, maxdisp, focal_coefficient, sparse):
-    N, C, H, W = est.shape
+def _focal_target(gt, H, W, maxdisp, focal_coefficient, sparse, dtype, device):
+    """everything of a level that does not depend on the estimate: the Laplace target distribution of the (pooled)
+    ground truth, times the focal weight, times the validity mask (reference loss.py:117-128, 206-240)"""
     gt = gt.view(gt.shape[0], 1, gt.shape[-2], gt.shape[-1]) if gt.dim() != 4 else gt
     scale = 1.0
     sgt = gt
@@ -32,19 +33,33 @@ def _focal_level(est, gt, maxdisp, focal_coefficient, sparse):
         pool = F.adaptive_max_pool2d if sparse else F.adaptive_avg_pool2d
         sgt = pool(gt / scale, (H, W))
     nd = int(maxdisp / scale)
-    mask = ((sgt > 0) & (sgt < nd)).to(est.dtype)
+    mask = ((sgt > 0) & (sgt < nd)).to(dtype)
     mgt = sgt * mask
-    inner = ((mgt > 0) & (mgt < nd - 1)).to(est.dtype)          # Disp2Prob.getProb, loss.py:87-90
-    index = torch.arange(0, nd, dtype=est.dtype, device=est.device).view(1, nd, 1, 1)
+    inner = ((mgt > 0) & (mgt < nd - 1)).to(dtype)          # Disp2Prob.getProb, loss.py:87-90
+    index = torch.arange(0, nd, dtype=dtype, device=device).view(1, nd, 1, 1)
     prob = F.softmax(-torch.abs(index - mgt * inner), dim=1) * inner + 1e-40
-    prob = prob * (mask.sum() >= 1.0).to(est.dtype)            # "no valid point" -> zero target (loss.py:224-227)
-    logp = F.log_softmax(est, dim=1)
+    prob = prob * (mask.sum() >= 1.0).to(dtype)            # "no valid point" -> zero target (loss.py:224-227)
     weight = (1.0 - prob).pow(-focal_coefficient)
+    return prob, weight, mask
+
+
+def _focal_level(est, target):
+    prob, weight, mask = target
+    logp = F.log_softmax(est, dim=1)
     return -((prob * logp) * weight * mask).sum(dim=1, keepdim=True).mean()
 
 
 def focal_loss(disp_ests, disp_gt, maxdisp, focal_coefficient, sparse):
-    """reference loss.py:16-24 (weights [0.5,0.7,1.0,1.2,1.5], silently truncating like zip does)."""
+    """reference loss.py:16-24 (weights [0.5,0.7,1.0,1.2,1.5], silently truncating like zip does).  The target side of
+    a level depends only on the ground truth and the level's resolution, so levels of equal resolution (all five in
+    DCANet) share one target instead of re-pooling / re-softmaxing the ground truth five times."""
     weights = [0.5, 0.7, 1.0, 1.2, 1.5]
-    return sum(w * _focal_level(est, disp_gt, maxdisp, focal_coefficient, sparse)
-               for est, w in zip(disp_ests, weights))
+    targets = {}
+    total = 0
+    for est, w in zip(disp_ests, weights):
+        key = (est.shape[-2], est.shape[-1], est.dtype, est.device)
+        if key not in targets:
+            targets[key] = _focal_target(disp_gt, est.shape[-2], est.shape[-1], maxdisp, focal_coefficient, sparse,
+                                         est.dtype, est.device)
+        total = total + w * _focal_level(est, targets[key])
+    return total
