@@ -1,8 +1,8 @@
 """How well-conditioned is the end-to-end train-mode gradient the GPU parity test gates?  Perturb the CPU oracle's
 inputs by a relative eps (random signs) and report the rel-L2 change of d(loss)/d(fL) -- the yardstick for the gate
 in tests/test_gpu_parity.py::test_golden_hot_path."""
-import sys, torch
-sys.path.insert(0, "/root/repo")
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import dcanet_oracle as O
 from oracle.seeded import seeded_tensor
 torch.set_num_threads(8)

@@ -1,6 +1,6 @@
 """bf16x3 vs fp32-MFMA 3x3x3 stride-1 conv on the shapes the networks use (ms per launch)."""
-import sys, torch
-sys.path.insert(0, "/root/repo")
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dcanet_amd
 from dcanet_amd import ops
 dev = "cuda"
