@@ -80,6 +80,10 @@ __device__ __forceinline__ float2 dca_bload2(__amdgpu_buffer_rsrc_t r, int byte_
   const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, dca_pred_off(byte_off, ok), 0, 0);
   return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
 }
+__device__ __forceinline__ void dca_bstore2(__amdgpu_buffer_rsrc_t r, float2 v, int byte_off, int ok) {
+  const u32x2 u = {__float_as_uint(v.x), __float_as_uint(v.y)};
+  __builtin_amdgcn_raw_buffer_store_b64(u, r, dca_pred_off(byte_off, ok), 0, 0);
+}
 __device__ __forceinline__ float4 dca_bload4(__amdgpu_buffer_rsrc_t r, int byte_off, int ok) {
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, dca_pred_off(byte_off, ok), 0, 0);
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
