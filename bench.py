@@ -240,6 +240,7 @@ def main():
     ap.add_argument("--mode", choices=["fwdbwd", "fwd"], default="fwdbwd")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=34)
+    ap.add_argument("--no-prepack", action="store_true", help="fwdbwd mode: re-lay-out each weight in its own launch")
     ap.add_argument("--graph", action="store_true",
                     help="replay the eval hot path (fwd) / the whole training step (fwdbwd, dcanet_amd.graph."
                          "GraphedTrainStep) as captured hipGraphs; off by default: at this shape the step is GPU bound "
@@ -263,7 +264,7 @@ def main():
 
     m = build_model(device)
     fL, fR, guid, gt = make_inputs(args.batch, rank, device)
-    train_graphed, graph_error = False, None
+    train_graphed, graph_error, prepack_n = False, None, 0
     if args.mode == "fwdbwd":
         m.train()
         fL.requires_grad_(); fR.requires_grad_()
@@ -271,6 +272,22 @@ def main():
         bucket = FlatGradBucket(params)
         opt = torch.optim.Adam(params, lr=1e-3, betas=(0.9, 0.999), capturable=bool(args.graph))
         step = lambda: train_step(m, fL, fR, guid, gt, bucket, opt)
+        if not args.graph and not args.no_prepack:
+            # all weight re-layouts of a step (forward + backward-data images of every conv) as ONE launch right after
+            # the optimizer update instead of ~130 five-microsecond launches (ops.PrepackPlan)
+            from dcanet_amd import ops as _ops
+            plan = _ops.PrepackPlan()
+            with plan.recording():
+                train_step(m, fL, fR, guid, gt, bucket, opt)
+            plan.finalize()
+            plan.refresh()
+
+            def step():
+                with plan.active():
+                    loss = train_step(m, fL, fR, guid, gt, bucket, opt)
+                plan.refresh()
+                return loss
+            prepack_n = plan.n
         if args.graph:
             # the whole step as hipGraph replays (dcanet_amd.graph.GraphedTrainStep); any capture problem -> eager
             try:
@@ -344,7 +361,9 @@ def main():
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "mode": args.mode, "hipgraph": bool(args.graph) if args.mode == "fwd" else train_graphed,
                        **({"hipgraph_error": graph_error} if graph_error else {}),
-                       "weight_prepack": "once (ops.frozen_weights)" if args.mode == "fwd" else "every step (weights change)"},
+                       "weight_prepack": "once (ops.frozen_weights)" if args.mode == "fwd" else
+                       (f"every step, {prepack_n} layouts in one launch (ops.PrepackPlan)" if prepack_n else
+                        "every step, one launch per layout")},
         }
         roof = kernel_roofline(device) if not args.shape else {}
         names = list(roof)

@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdca_hip.so")
-SOURCES = ["conv3d_mfma.hip", "conv3d_winograd.hip", "conv3d_bf16x3.hip", "conv3d_wgrad.hip", "conv3d_wgrad_bf16x3.hip", "conv3d_c1.hip", "volume.hip", "up_softargmin.hip", "pointwise.hip", "context_attention.hip"]
+SOURCES = ["conv3d_mfma.hip", "conv3d_winograd.hip", "conv3d_bf16x3.hip", "prep_many.hip", "conv3d_wgrad.hip", "conv3d_wgrad_bf16x3.hip", "conv3d_c1.hip", "volume.hip", "up_softargmin.hip", "pointwise.hip", "context_attention.hip"]
 
 
 def _stale() -> bool:

@@ -22,6 +22,7 @@ SIGNATURES = {
     "dca_conv3d_forward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _f] + [_i] * 16 + [_p]),
     "dca_conv3d_wino_prep_weight": (_i, [_p, _p] + [_i] * 7 + [_p]),
     "dca_conv3d_wino_forward": (_i, [_p] * 7 + [_f] + [_i] * 9 + [_p]),
+    "dca_conv3d_prep_many": (_i, [_p, _i, _p]),
     "dca_conv3d_x3_weight_bytes": (_l, [_i, _i]),
     "dca_conv3d_x3_prep_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "dca_conv3d_x3_forward": (_i, [_p] * 7 + [_f] + [_i] * 6 + [_p]),

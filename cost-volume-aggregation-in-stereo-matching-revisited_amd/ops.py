@@ -252,7 +252,8 @@ def _prep_weight(w_src, A, B, K, src_ab, flip, ksize, stride, transposed, b_off=
         _chk(_L().dca_conv3d_prep_weight(_ptr(w_src), _ptr(wt), A, Bn, Apad, Bpad, K, int(src_ab), int(flip), B, b_off,
                                          _stream()), "dca_conv3d_prep_weight")
         return wt
-    return _memo(("prep", A, B, K, int(src_ab), int(flip), Apad, Bpad, b_off, Bn), (w_src,), build), Apad
+    return _memo(("prep", A, B, K, int(src_ab), int(flip), Apad, Bpad, b_off, Bn), (w_src,), build,
+                 (0, A, Bn, Apad, Bpad, K, int(src_ab), int(flip), B, b_off)), Apad
 
 
 def _out_dims(dims, ksize, stride, transposed):
@@ -289,7 +290,8 @@ def _conv_sliced(x, x2, w_src, A, B, K, src_ab, flip, ksize, stride, transposed,
             _chk(lib.dca_conv3d_x3_prep_weight(_ptr(w_src), _ptr(w3), A, B, int(src_ab), int(flip), _stream()),
                  "dca_conv3d_x3_prep_weight")
             return w3
-        wx = _memo(("x3prep", A, B, int(src_ab), int(flip)), (w_src,), build_x3)
+        wx = _memo(("x3prep", A, B, int(src_ab), int(flip)), (w_src,), build_x3,
+                   (1, A, B, 0, 0, 27, int(src_ab), int(flip), B, 0))
         _chk(lib.dca_conv3d_x3_forward(_ptr(x), _ptr(wx), _ptr(y), _ptr(scale), _ptr(shift), _ptr(res_pre),
                                        _ptr(res_post), float(slope), N, A, B, Di, Hi, Wi, _stream()),
              "dca_conv3d_x3_forward")
@@ -572,8 +574,93 @@ class frozen_weights:
         return False
 
 
-def _memo(key, tensors, build):
-    """build() once per (key, identity of `tensors`) inside a frozen_weights() context; plain build() otherwise"""
+_PLAN_RECORDER = None   # PrepackPlan being recorded (process-wide, see the class)
+_PLAN_ACTIVE = None     # {cache key: packed tensor} of the active PrepackPlan
+
+
+class PrepackPlan:
+    """Training helper: the weight re-layouts of a whole step as ONE launch (dca_conv3d_prep_many).
+
+        plan = ops.PrepackPlan()
+        with plan.recording():          # one ordinary step: notes every (parameter, layout) the step asks for
+            step()
+        plan.finalize()
+        loop:   with plan.active(): step_forward_backward(); optimizer.step(); plan.refresh()
+
+    `refresh()` re-packs all recorded layouts from the current parameter values; inside `active()` the convolutions pick
+    the pre-packed images up instead of launching their own prep kernels.  Only layouts whose source is a leaf tensor
+    that owns its storage (a parameter) are planned; anything else keeps packing per call.  The recording / active
+    state is per PROCESS, not per thread: backward-data layouts are requested from the autograd engine's thread."""
+
+    def __init__(self):
+        self.entries = {}      # cache key -> (packed tensor, descriptor tuple, source tensors)
+        self.table = None
+        self.n = 0
+
+    def recording(self):
+        plan = self
+
+        class _Rec:
+            def __enter__(self_inner):
+                global _PLAN_RECORDER
+                self_inner.prev, _PLAN_RECORDER = _PLAN_RECORDER, plan
+
+            def __exit__(self_inner, *exc):
+                global _PLAN_RECORDER
+                _PLAN_RECORDER = self_inner.prev
+                return False
+        return _Rec()
+
+    def finalize(self):
+        import struct
+        rows = []
+        for out, desc, tensors in self.entries.values():
+            kind, A, Bn, Apad, Bpad, K, src_ab, flip, Btotal, b_off = desc
+            nch = (A + 15) // 16
+            total = out.numel()
+            rows.append(struct.pack("<QQ12iq", tensors[0].data_ptr(), out.data_ptr(), kind, A, Bn, Apad, Bpad, K, src_ab,
+                                    flip, Btotal, b_off, nch, 0, total))
+        self.n = len(rows)
+        if self.n:
+            dev = next(iter(self.entries.values()))[0].device
+            self.table = torch.frombuffer(bytearray(b"".join(rows)), dtype=torch.uint8).to(dev)
+        return self
+
+    def refresh(self):
+        if self.n:
+            _chk(_L().dca_conv3d_prep_many(_ptr(self.table), self.n, _stream()), "dca_conv3d_prep_many")
+
+    def active(self):
+        plan = self
+
+        class _Act:
+            def __enter__(self_inner):
+                global _PLAN_ACTIVE
+                self_inner.prev = _PLAN_ACTIVE
+                _PLAN_ACTIVE = {k: out for k, (out, _, _t) in plan.entries.items()}
+
+            def __exit__(self_inner, *exc):
+                global _PLAN_ACTIVE
+                _PLAN_ACTIVE = self_inner.prev
+                return False
+        return _Act()
+
+
+def _memo(key, tensors, build, desc=None):
+    """build() once per (key, identity of `tensors`) inside a frozen_weights() / PrepackPlan.active() context; plain
+    build() otherwise (a PrepackPlan being recorded also notes `desc`, the dca_conv3d_prep_many descriptor)"""
+    rec = _PLAN_RECORDER
+    if rec is not None:
+        out = build()
+        t = tensors[0] if tensors else None
+        if desc is not None and t is not None and t.is_leaf and t._base is None:
+            rec.entries[(key,) + tuple((id(x), x.data_ptr()) for x in tensors)] = (out, desc, tensors)
+        return out
+    act = _PLAN_ACTIVE
+    if act is not None and desc is not None:
+        hit = act.get((key,) + tuple((id(x), x.data_ptr()) for x in tensors))
+        if hit is not None:
+            return hit
     cache = getattr(_tls, "frozen", None)
     if cache is None or (tensors and tensors[0].is_cuda and torch.cuda.is_current_stream_capturing()):
         return build()

@@ -101,6 +101,13 @@ int dca_conv3d_wino_forward(const float* x, const float* ug, float* y, const flo
                             const float* res_pre, const float* res_post, float slope, int N, int Cin, int Cout,
                             int CinPad, int CoutTotal, int co_off, int D, int H, int W, hipStream_t stream);
 
+/* Batched weight re-layout: ONE launch for n descriptors of dca_conv3d_prep_weight (kind 0) / dca_conv3d_x3_prep_weight
+ * (kind 1) work (prep_many.hip) -- a training step re-packs every conv weight after the optimizer update, and ~130
+ * separate 5-us launches cost more than the work.  table: n device-resident 72-byte records
+ *   { const float* src; void* dst; int kind, A, Bn, Apad, Bpad, K, src_ab, flip, Btotal, b_off, NCH, pad; long total; }
+ * (kind 1 uses A, Bn, src_ab, flip, NCH = ceil(A/16), total = dca_conv3d_x3_weight_bytes/2; kind 0 total = K*Apad*Bpad). */
+int dca_conv3d_prep_many(const void* table, int n, hipStream_t stream);
+
 /* "bf16x3" split-precision 3x3x3 / stride-1 / pad-1 convolution (conv3d_bf16x3.hip): every fp32 operand is split exactly
  * into three bf16 terms and the six partial products >= 2^-16 run on the bf16 matrix pipe with fp32 accumulation --
  * fp32-grade results (dropped terms <= 2^-23 relative, no range restriction) at 2.67x fewer matrix-pipe cycles than

@@ -770,3 +770,47 @@ def test_graphed_train_step_matches_eager():
     torch.cuda.synchronize()
     worst = max(((a - b).abs().max() / (b.abs().max() + 1e-12)).item() for a, b in zip(pg, pe))
     assert worst == 0.0, worst                   # same kernels, same order, no atomics: bitwise
+
+
+def test_prepack_plan_matches_per_call_packing():
+    """ops.PrepackPlan: the batched re-layout launch writes bit-identical images, convolutions inside plan.active() use
+    them (outputs and gradients bitwise equal to per-call packing), and refresh() tracks in-place weight updates"""
+    _, ops = _mods()
+    import torch.nn as nn
+    torch.manual_seed(0)
+    convs = [nn.Conv3d(32, 32, 3, 1, 1, bias=False), nn.Conv3d(32, 64, 3, 2, 1, bias=False),
+             nn.ConvTranspose3d(64, 32, 3, 2, 1, 1, bias=False), nn.Conv3d(40, 32, 3, 1, 1, bias=False)]
+    for c in convs:
+        c.to(DEV)
+    x = seeded_tensor("pp.x", (1, 32, 4, 8, 16)).to(DEV).requires_grad_()
+    x40 = seeded_tensor("pp.x40", (1, 40, 4, 8, 16)).to(DEV).requires_grad_()
+
+    def run():
+        y = ops.conv3d(x, convs[0].weight, 1, False)
+        z = ops.conv3d(ops.conv3d(y, convs[1].weight, 2, False), convs[2].weight, 2, True)
+        u = ops.conv3d(x40, convs[3].weight, 1, False)
+        loss = (z * z).sum() + (u * y).sum()
+        ps = [c.weight for c in convs]
+        return [loss.detach()] + list(torch.autograd.grad(loss, [x, x40] + ps))
+    ref = run()
+    plan = ops.PrepackPlan()
+    with plan.recording():
+        run()
+    plan.finalize()
+    assert plan.n >= 6                                  # forward + backward-data layouts of the 3x3x3 convs
+    for out, desc, tensors in plan.entries.values():    # refresh() reproduces the recorded images bit for bit
+        keep = out.clone(); out.zero_()
+        plan.refresh()
+        assert torch.equal(out, keep)
+        break
+    with plan.active():
+        got = run()
+    assert all(torch.equal(a, b) for a, b in zip(got, ref))
+    with torch.no_grad():
+        for c in convs:
+            c.weight.mul_(1.5)
+    plan.refresh()
+    ref2 = run()
+    with plan.active():
+        got2 = run()
+    assert all(torch.equal(a, b) for a, b in zip(got2, ref2)) and not torch.equal(ref2[0], ref[0])
