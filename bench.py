@@ -3,6 +3,9 @@
 
     python bench.py --gpus N --steps K --warmup W [--mode fwdbwd|fwd] [--batch B]
 
+Per-GPU batch (weak scaling): 4 stereo pairs for the training step -- BASELINE.json configs[2] "fwd+bwd, batch=4" and
+configs[3] "8 GPUs, batch=32" -- and 1 for the eval forward (configs[1]); `value` counts cost volumes, not steps.
+
 One *step* = one pass of the hot path over one batch of synthetic SceneFlow-test-shaped input
 (544x960, D=192 -> 1/4-res features (B,320,136,240) x2, seed 1234+rank, already resident in HBM):
 
@@ -236,7 +239,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=1, help="stereo pairs per GPU (weak scaling)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="stereo pairs per GPU (weak scaling); default 4 for the training step -- BASELINE.json configs[2] "
+                         "(fwd+bwd, batch=4) and configs[3] (8 GPUs, batch=32) -- and 1 for the eval forward (configs[1])")
     ap.add_argument("--mode", choices=["fwdbwd", "fwd"], default="fwdbwd")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=34)
@@ -249,6 +254,8 @@ def main():
                                                   "256x512x64 plumbing); default = BASELINE's 544x960x192")
     args = ap.parse_args()
 
+    if args.batch is None:
+        args.batch = 4 if args.mode == "fwdbwd" else 1
     global H_IMG, W_IMG, MAXDISP
     if args.shape:
         H_IMG, W_IMG, MAXDISP = (int(v) for v in args.shape.lower().split("x"))
