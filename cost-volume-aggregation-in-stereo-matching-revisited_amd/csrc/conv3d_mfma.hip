@@ -12,6 +12,7 @@
 // the per-chunk weights staged in LDS.  The same three kernels serve the backward-data passes with
 // re-laid-out weights (see dca_conv3d_prep_weight).
 #include "dca_common.h"
+#include <stdlib.h>
 #include "../../include/dca_hip.h"
 
 struct ConvArgs {
@@ -649,5 +650,8 @@ extern "C" int dca_conv3d_forward(const float* x, const float* x2, const float* 
     return launch_conv3<1, 2, 4, 4, 8, 16>(a, vec, stream);
   }
   DCA_REQUIRE(stride == 2 && Do == (Di + 1) / 2 && Ho == (Hi + 1) / 2 && Wo == (Wi + 1) / 2);
+  // Few big tiles quantise badly (816 workgroups of 2 x 4 x 32 on 512 slots at 24 x 68 x 120): below ~4 rounds use
+  // 1 x 4 x 32 tiles with 2-channel chunks (29 KB of LDS, 123 registers -> four workgroups per CU): 265 -> 243 us.
+  if ((long)N * cdiv(Do, 2) * cdiv(Ho, 4) * cdiv(Wo, 32) < 2048) return launch_conv3<2, 2, 2, 1, 4, 32>(a, vec, stream);
   return launch_conv3<2, 2, 4, 2, 4, 32>(a, vec, stream);
 }
