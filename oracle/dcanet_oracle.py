@@ -289,6 +289,144 @@ def baseline_shapes(num_groups: int = 40):
 
 
 # --------------------------------------------------------------------------------------
+# SURVEY 8(f) neighbours of the path: 2D feature extractor, Guidance, convex up-sampler, whole model, losses
+# --------------------------------------------------------------------------------------
+def _bn2(sd: SD, p: str, x, training: bool):
+    """nn.BatchNorm2d defaults (same semantics as _bn)."""
+    return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"],
+                        training, 0.1, 1e-5)
+
+
+def _convbn2(sd: SD, p: str, x, stride, pad, dilation, training):
+    """`convbn` models/submodule.py:115-118: Conv2d(bias=False, padding = dilation if dilation > 1 else pad) + BN."""
+    y = F.conv2d(x, sd[p + ".0.weight"], None, stride, dilation if dilation > 1 else pad, dilation)
+    return _bn2(sd, p + ".1", y, training)
+
+
+def _basic_block(sd: SD, p: str, x, stride, pad, dilation, training):
+    """BasicBlock models/submodule.py:251-273: convbn+ReLU, convbn, (+ downsample), `out += x`, NO final ReLU."""
+    out = F.relu(_convbn2(sd, p + ".conv1.0", x, stride, pad, dilation, training))
+    out = _convbn2(sd, p + ".conv2", out, 1, pad, dilation, training)
+    if (p + ".downsample.0.weight") in sd:
+        x = _bn2(sd, p + ".downsample.1", F.conv2d(x, sd[p + ".downsample.0.weight"], None, stride), training)
+    return out + x
+
+
+def feature_extraction(sd: SD, x, training: bool, p: str = "feature_extraction"):
+    """models/gwcnet_dca_g.py:13-66.  Returns (gwc_feature (B,320,H/4,W/4), concat_feature or None)."""
+    for i, stride in ((0, 2), (2, 1), (4, 1)):                                      # firstconv :19-24
+        x = F.relu(_convbn2(sd, f"{p}.firstconv.{i}", x, stride, 1, 1, training))
+    for layer, blocks, stride, dil in (("layer1", 3, 1, 1), ("layer2", 16, 2, 1), ("layer3", 3, 1, 1),
+                                       ("layer4", 3, 1, 2)):                        # :26-29
+        for b in range(blocks):
+            x = _basic_block(sd, f"{p}.{layer}.{b}", x, stride if b == 0 else 1, 1, dil, training)
+        if layer == "layer2":
+            l2 = x
+        elif layer == "layer3":
+            l3 = x
+    gwc = torch.cat((l2, l3, x), dim=1)                                             # :60
+    if (p + ".lastconv.2.weight") not in sd:
+        return gwc, None
+    c = F.relu(_convbn2(sd, p + ".lastconv.0", gwc, 1, 1, 1, training))              # :31-35
+    return gwc, F.conv2d(c, sd[p + ".lastconv.2.weight"])
+
+
+def _residual_block(sd: SD, p: str, x, stride, training):
+    """ResidualBlock models/submodule.py:305-355, norm_fn='batch'.  `norm3` is the same module as `downsample.1`:
+    load_state_dict fills `downsample.1.*` last, so those keys hold the live values."""
+    y = F.relu(_bn2(sd, p + ".norm1", F.conv2d(x, sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], stride, 1), training))
+    y = F.relu(_bn2(sd, p + ".norm2", F.conv2d(y, sd[p + ".conv2.weight"], sd[p + ".conv2.bias"], 1, 1), training))
+    if stride != 1:
+        x = _bn2(sd, p + ".downsample.1",
+                 F.conv2d(x, sd[p + ".downsample.0.weight"], sd[p + ".downsample.0.bias"], stride), training)
+    return F.relu(x + y)
+
+
+def guidance(sd: SD, x, training: bool, p: str = "guidance"):
+    """Guidance models/submodule.py:395-460 -> g (B,64,H/4,W/4).  (`norm1` is shared with `conv_start.1`, whose keys
+    are loaded last.)"""
+    x = F.relu(_bn2(sd, p + ".conv_start.1",
+                    F.conv2d(x, sd[p + ".conv_start.0.weight"], sd[p + ".conv_start.0.bias"], 2, 3), training))
+    for layer, stride in (("layer1", 1), ("layer2", 2)):
+        x = _residual_block(sd, f"{p}.{layer}.0", x, stride, training)
+        x = _residual_block(sd, f"{p}.{layer}.1", x, 1, training)
+    for i in (0, 1):                                                                 # BasicConv :276-302
+        x = F.relu(_bn2(sd, f"{p}.conv_g0.{i}.bn", F.conv2d(x, sd[f"{p}.conv_g0.{i}.conv.weight"], None, 1, 1), training))
+    return F.conv2d(x, sd[p + ".guidance.weight"], None, 1, 1)
+
+
+def convex_upsample(mask_logits, disp):
+    """PropgationNet_4x.forward after its conv (models/submodule.py:366-373), written with explicit
+    shifts instead of unfold: mask_logits (B,144,h,w) with channel = k*16 + i*4 + j, softmax over the 9 neighbours k,
+    up[b,0,4y+i,4x+j] = sum_k mask[k,i,j,y,x] * 4*disp[y+k//3-1, x+k%3-1] (zero padded)."""
+    b, _, h, w = disp.shape
+    m = F.softmax(mask_logits.view(b, 9, 4, 4, h, w), dim=1)
+    dp = F.pad(4 * disp, (1, 1, 1, 1))
+    up = 0
+    for k in range(9):
+        ky, kx = k // 3, k % 3
+        up = up + m[:, k] * dp[:, :, ky:ky + h, kx:kx + w].reshape(b, 1, 1, h, w)
+    return up.permute(0, 3, 1, 4, 2).reshape(b, 1, 4 * h, 4 * w)
+
+
+def prop(sd: SD, g, disp, training: bool, p: str = "prop"):
+    """PropgationNet_4x models/submodule.py:357-373."""
+    c = F.relu(_convbn2(sd, p + ".conv.0", g, 1, 1, 1, training))
+    return convex_upsample(F.conv2d(c, sd[p + ".conv.2.weight"], None, 1, 1), disp)
+
+
+def whole_model(sd: SD, left, right, maxdisp: int, training: bool, num_groups: int = 40):
+    """GwcNet.forward (models/gwcnet_dca_g.py:209-282) end to end.  Returns the reference's own return value:
+    train -> ([pred0,pred_dca1,pred_dca2,pred1,pred2], [pred_dca3,pred4]); eval -> (pred4, prob_volume2.squeeze(1)),
+    plus a dict of intermediates as a third element."""
+    fL, cL = feature_extraction(sd, left, training)                                   # :213
+    fR, cR = feature_extraction(sd, right, training)                                  # :214
+    g = guidance(sd, left, training)                                                  # :215
+    r = hot_path(sd, fL, fR, maxdisp, training, num_groups, cL, cR)                   # :216-239, 244-275
+    pred4 = prop(sd, g, r["pred4_q"], training)                                       # :240
+    aux = dict(r, gwc_feature=fL, guidance=g)
+    if training:
+        return [r["pred0"], r["pred_dca1"], r["pred_dca2"], r["pred1"], r["pred2"]], [r["pred_dca3"], pred4], aux
+    return pred4, r["prob_volume2"].squeeze(1), aux
+
+
+def model_loss(disp_ests, disp_gt, mask):
+    """models/loss.py:6-14: 1.8 / 2.1 weighted smooth-L1 (beta 1, mean) over the masked pixels."""
+    weights = [1.8, 2.1]
+    assert len(weights) == len(disp_ests)
+    return sum(w * F.smooth_l1_loss(e[mask], disp_gt[mask], reduction="mean") for e, w in zip(disp_ests, weights))
+
+
+def stereo_focal_loss_level(est, gt, max_disp, focal_coefficient, sparse):
+    """StereoFocalLoss.loss_per_level with LaplaceDisp2Prob (models/loss.py:206-240, 60-128), line by line."""
+    N, C, H, W = est.shape
+    sgt, scale = gt.clone(), 1.0
+    if gt.shape[-2] != H or gt.shape[-1] != W:                                        # :210-215
+        scale = gt.shape[-1] / (W * 1.0)
+        sgt = (F.adaptive_max_pool2d if sparse else F.adaptive_avg_pool2d)(gt.clone() / scale, (H, W))
+    upper = int(max_disp / scale)                                                     # :220-221
+    mask = ((sgt > 0) & (sgt < upper)).to(sgt.dtype)
+    if mask.sum() < 1.0:                                                              # :224-227
+        prob = torch.zeros_like(est)
+    else:
+        mgt = sgt * mask                                                              # :230
+        nd = upper
+        index = torch.arange(0, nd, dtype=mgt.dtype).view(1, nd, 1, 1)
+        inner = ((mgt > 0) & (mgt < nd - 1)).to(mgt.dtype)                            # :87-89 (end_disp = nd - 1, :70)
+        prob = F.softmax(-torch.abs(index - mgt * inner), dim=1) * inner + 1e-40      # :90-96, 124-126
+    logp = F.log_softmax(est, dim=1)                                                  # :236
+    weight = (1.0 - prob).pow(-focal_coefficient)                                     # :237
+    return -((prob * logp) * weight * mask).sum(dim=1, keepdim=True).mean()           # :238
+
+
+def focal_loss(disp_ests, disp_gt, maxdisp, focal_coefficient, sparse):
+    """models/loss.py:16-24."""
+    weights = [0.5, 0.7, 1.0, 1.2, 1.5]
+    return sum(w * stereo_focal_loss_level(e, disp_gt, maxdisp, focal_coefficient, sparse)
+               for e, w in zip(disp_ests, weights))
+
+
+# --------------------------------------------------------------------------------------
 # Deterministic, well-conditioned test weights (SURVEY Appendix D)
 # --------------------------------------------------------------------------------------
 GAIN = 1.5

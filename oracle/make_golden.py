@@ -214,6 +214,68 @@ def gen_hot_path():
                 npz(stem, pred4_q=pred4, prob_volume2=prob2, gfL=g[0][:, ::16], gfR=g[1][:, ::16])
 
 
+# ------------------------------------------------------------------ whole model: GwcNet.forward(left, right, disp_true)
+def gen_whole_model():
+    """The real boundary: the reference's `GwcNet(32, G / GC)` -- 2D feature extractor, Guidance,
+    hot path, convex up-sampler -- on a (1,3,64,128) pair with Appendix-D weights (incl. the residual-gamma x0.25 rule),
+    eval tuple and train lists (gwcnet_dca_g.py:209-282), plus `Guidance` and `PropgationNet_4x` alone."""
+    left = seeded_tensor("whole.left", (1, 3, 64, 128))
+    right = seeded_tensor("whole.right", (1, 3, 64, 128))
+    for variant, concat in (("g", False), ("gc", True)):
+        for training in (False, True):
+            m = ref_dca.GwcNet(32, use_concat_volume=concat)
+            load_seeded(m)
+            m.train(training)
+            stem = f"whole_{variant}_{'train' if training else 'eval'}"
+            L = left.clone().requires_grad_()
+            R = right.clone().requires_grad_()
+            feat = m.feature_extraction(L)["gwc_feature"].detach()
+            guid = m.guidance(L)["g"].detach()
+            if training:
+                # the two probe calls above moved the BN running stats: reload, so the fixture = one clean forward
+                load_seeded(m)
+                m.train(True)
+            out = m(L, R, None)
+            if training:
+                probs, disps = out
+                outs = list(probs) + list(disps)
+                tags = [f"whole.g{i}" for i in range(len(outs))]
+                params = [m.feature_extraction.firstconv[0][0].weight, m.feature_extraction.layer4[2].conv2[0].weight,
+                          m.guidance.conv_start[0].weight, m.guidance.guidance.weight, m.prop.conv[2].weight,
+                          m.prop.conv[0][1].bias, m.dres0[0][0].weight, m.cva2.cost_agg.conv3[0].weight]
+                g = grads_of(outs, tags, [L, R] + params)
+                npz(stem, pred0=probs[0], pred_dca1=probs[1], pred_dca2=probs[2], pred1=probs[3], pred2=probs[4],
+                    pred_dca3=disps[0], pred4=disps[1], gwc_feature=feat[:, ::16], guidance=guid[:, ::8],
+                    gL=g[0], gR=g[1], g_fe_first_w=g[2], g_fe_l4_w=g[3][::8], g_guid_start_w=g[4], g_guid_out_w=g[5][::4],
+                    g_prop_w=g[6][::8], g_prop_bnb=g[7], g_dres0_w=g[8], g_cva2_deconv_w=g[9],
+                    rm_fe_first=m.feature_extraction.firstconv[0][1].running_mean,
+                    rv_prop=m.prop.conv[0][1].running_var, nbt=m.dres0[0][1].num_batches_tracked)
+            else:
+                pred4, prob2 = out
+                g = grads_of([pred4], ["whole.g_eval"], [L, R])
+                npz(stem, pred4=pred4, prob_volume2=prob2, gwc_feature=feat[:, ::16], guidance=guid[:, ::8],
+                    gL=g[0], gR=g[1])
+    # Guidance and the convex up-sampler alone (submodule.py:395-460, 357-373)
+    for training in (False, True):
+        gnet = ref_sub.Guidance(64)
+        sd = O.seeded_state_dict({"guidance." + k: tuple(v.shape) for k, v in gnet.state_dict().items()})
+        gnet.load_state_dict({k[len("guidance."):]: v for k, v in sd.items()}, strict=True)
+        gnet.train(training)
+        x = seeded_tensor("guid.x", (2, 3, 32, 64)).requires_grad_()
+        gout = gnet(x)["g"]
+        gg = grads_of([gout], ["guid.g"], [x, gnet.conv_start[0].weight, gnet.layer2[0].downsample[0].bias])
+        prop = ref_sub.PropgationNet_4x(64)
+        sd = O.seeded_state_dict({"prop." + k: tuple(v.shape) for k, v in prop.state_dict().items()})
+        prop.load_state_dict({k[len("prop."):]: v for k, v in sd.items()}, strict=True)
+        prop.train(training)
+        gd = seeded_tensor("prop.guid", (2, 64, 6, 10)).requires_grad_()
+        disp = (seeded_tensor("prop.disp", (2, 1, 6, 10)) * 2 + 5).requires_grad_()
+        up = prop(gd, disp)
+        gp = grads_of([up], ["prop.g"], [gd, disp, prop.conv[2].weight])
+        npz(f"guidance_prop_{'train' if training else 'eval'}", g=gout[:, ::4], g_x=gg[0], g_start_w=gg[1], g_ds_b=gg[2],
+            up=up, gp_guid=gp[0], gp_disp=gp[1], gp_w=gp[2][::8])
+
+
 def gen_baseline():
     """Baseline gwcnet.GwcNet (3 stacked hourglasses), training branch, from the 1/4-res features."""
     m = ref_gwc.GwcNet(32, use_concat_volume=False)
@@ -274,7 +336,7 @@ def gen_state_dict_keys():
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["volumes", "inject", "attention", "cva", "magg", "hot", "keys", "losses", "baseline"]
+    which = sys.argv[1:] or ["volumes", "inject", "attention", "cva", "magg", "hot", "keys", "losses", "baseline", "whole"]
     with torch.enable_grad():
         if "volumes" in which: gen_volumes()
         if "inject" in which: gen_context_inject()
@@ -285,3 +347,4 @@ if __name__ == "__main__":
         if "keys" in which: gen_state_dict_keys()
         if "losses" in which: gen_losses()
         if "baseline" in which: gen_baseline()
+        if "whole" in which: gen_whole_model()

@@ -228,3 +228,97 @@ def test_baseline_gwcnet(golden):
     close_l2(gr[0][:, ::16], g["gfL"], 2e-3, "gfL"); close_l2(gr[1][:, ::16], g["gfR"], 2e-3, "gfR")
     for got, name in zip(gr[2:], ["g_d2c5_w", "g_d3c3_w", "g_d4r2_w", "g_d2c4_bnw"]):
         close_l2(thin(got), g[name], 2e-3, name)
+
+
+# ------------------------------------------------------------------ the real boundary, whole model
+def _whole_sd(variant):
+    import json
+    import os
+    from conftest import GOLDEN
+    with open(os.path.join(GOLDEN, "state_dict_keys.json")) as f:
+        shapes = json.load(f)[variant]
+    return O.seeded_state_dict({k: tuple(v) for k, v in shapes.items()})
+
+
+WHOLE_GRAD_KEYS = ["feature_extraction.firstconv.0.0.weight", "feature_extraction.layer4.2.conv2.0.weight",
+                   "guidance.conv_start.0.weight", "guidance.guidance.weight", "prop.conv.2.weight",
+                   "prop.conv.0.1.bias", "dres0.0.0.weight", "cva2.cost_agg.conv3.0.weight"]
+WHOLE_GRAD_NAMES = ["g_fe_first_w", "g_fe_l4_w", "g_guid_start_w", "g_guid_out_w", "g_prop_w", "g_prop_bnb", "g_dres0_w",
+                    "g_cva2_deconv_w"]
+WHOLE_GRAD_STRIDE = [1, 8, 1, 4, 8, 1, 1, 1]
+
+
+@pytest.mark.parametrize("variant", ["g", "gc"])
+@pytest.mark.parametrize("training", [False, True])
+def test_whole_model(golden, variant, training):
+    """GwcNet.forward(left, right, disp_true) of the reference (gwcnet_dca_g.py:209-282) on (1,3,64,128): 2D extractor,
+    Guidance, hot path, convex up-sampler -- oracle restatement vs the reference's own outputs."""
+    g = golden(f"whole_{variant}_{'train' if training else 'eval'}")
+    sd = _whole_sd(variant)
+    for k in WHOLE_GRAD_KEYS:
+        sd[k].requires_grad_()
+    L = seeded_tensor("whole.left", (1, 3, 64, 128)).requires_grad_()
+    R = seeded_tensor("whole.right", (1, 3, 64, 128)).requires_grad_()
+    out = O.whole_model(sd, L, R, 32, training)
+    aux = out[2]
+    close(aux["gwc_feature"][:, ::16], g["gwc_feature"], 2e-5, "gwc_feature")
+    close(aux["guidance"][:, ::8], g["guidance"], 2e-5, "guidance")
+    if training:
+        probs, disps = out[0], out[1]
+        for k, v in zip(["pred0", "pred_dca1", "pred_dca2", "pred1", "pred2"], probs):
+            close(v, g[k], 2e-5, k)
+        close(disps[0], g["pred_dca3"], 2e-5, "pred_dca3")
+        close(disps[1], g["pred4"], 2e-5, "pred4")
+        gr = grads_of(list(probs) + list(disps), [f"whole.g{i}" for i in range(7)], [L, R] + [sd[k] for k in WHOLE_GRAD_KEYS])
+        close_l2(gr[0], g["gL"], 5e-3, "gL"); close_l2(gr[1], g["gR"], 5e-3, "gR")
+        for got, name, st in zip(gr[2:], WHOLE_GRAD_NAMES, WHOLE_GRAD_STRIDE):
+            close_l2(thin(got[::st]), g[name], 1e-2 if name.endswith("bnb") else 5e-3, name)
+        close(sd["feature_extraction.firstconv.0.1.running_mean"], g["rm_fe_first"], 1e-5, "running_mean")
+        close(sd["prop.conv.0.1.running_var"], g["rv_prop"], 1e-5, "running_var")
+    else:
+        close(out[0], g["pred4"], 2e-5, "pred4")
+        close(out[1], g["prob_volume2"], 2e-5, "prob_volume2")
+        gr = grads_of([out[0]], ["whole.g_eval"], [L, R])
+        close(gr[0], g["gL"], 2e-4, "gL"); close(gr[1], g["gR"], 2e-4, "gR")
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_guidance_and_convex_upsampler(golden, training):
+    """Guidance (submodule.py:395-460) and PropgationNet_4x (submodule.py:357-373) alone."""
+    g = golden(f"guidance_prop_{'train' if training else 'eval'}")
+    sd = _whole_sd("g")
+    sd = {k: v.clone() for k, v in sd.items() if k.startswith(("guidance.", "prop."))}
+    for k in ("guidance.conv_start.0.weight", "guidance.layer2.0.downsample.0.bias", "prop.conv.2.weight"):
+        sd[k].requires_grad_()
+    x = seeded_tensor("guid.x", (2, 3, 32, 64)).requires_grad_()
+    gout = O.guidance(sd, x, training)
+    close(gout[:, ::4], g["g"], 2e-5, "g")
+    gg = grads_of([gout], ["guid.g"], [x, sd["guidance.conv_start.0.weight"], sd["guidance.layer2.0.downsample.0.bias"]])
+    close_l2(gg[0], g["g_x"], 1e-3, "g_x"); close_l2(gg[1], g["g_start_w"], 1e-3, "g_start_w")
+    if not training:     # under batch statistics a bias in front of a BN has a (numerically noisy) ~zero gradient
+        close_l2(gg[2], g["g_ds_b"], 1e-3, "g_ds_b")
+    gd = seeded_tensor("prop.guid", (2, 64, 6, 10)).requires_grad_()
+    disp = (seeded_tensor("prop.disp", (2, 1, 6, 10)) * 2 + 5).requires_grad_()
+    up = O.prop(sd, gd, disp, training)
+    close(up, g["up"], 2e-5, "up")
+    gp = grads_of([up], ["prop.g"], [gd, disp, sd["prop.conv.2.weight"]])
+    close_l2(gp[0], g["gp_guid"], 1e-3, "gp_guid"); close_l2(gp[1], g["gp_disp"], 1e-4, "gp_disp")
+    close_l2(gp[2][::8], g["gp_w"], 1e-3, "gp_w")
+
+
+def test_losses(golden):
+    """oracle focal_loss / model_loss vs the reference's (models/loss.py), incl. gradients and the sparse variant."""
+    g = golden("losses")
+    gt = T(g["gt"])
+    ests = [torch.softmax(seeded_tensor(f"loss.e{i}", (2, 8, 8, 16)), 1).requires_grad_() for i in range(5)]
+    fl = O.focal_loss(ests, gt, 32, 5.0, False)
+    close(fl, g["focal"], 1e-5, "focal")
+    close(O.focal_loss(ests, gt, 32, 5.0, True), g["focal_sparse"], 1e-5, "focal_sparse")
+    ge = torch.autograd.grad(fl, ests)
+    close(ge[0], g["gfocal0"], 1e-5, "gfocal0"); close(ge[4], g["gfocal4"], 1e-5, "gfocal4")
+    d0 = (seeded_tensor("loss.d0", (2, 1, 32, 64)) * 3 + gt).requires_grad_()
+    d1 = (seeded_tensor("loss.d1", (2, 1, 32, 64)) * 0.3 + gt).requires_grad_()
+    ml = O.model_loss([d0, d1], gt, (gt < 32) & (gt > 0))
+    close(ml, g["model"], 1e-5, "model")
+    gd = torch.autograd.grad(ml, [d0, d1])
+    close(gd[0], g["gd0"], 1e-5, "gd0"); close(gd[1], g["gd1"], 1e-5, "gd1")
