@@ -276,6 +276,24 @@ def gen_whole_model():
             up=up, gp_guid=gp[0], gp_disp=gp[1], gp_w=gp[2][::8])
 
 
+def gen_init():
+    """a10: the reference's weight init (gwcnet_dca_g.py:173-185) under a fixed torch seed: per-key fingerprints
+    (sum, abs-sum, first 4 values) of the freshly constructed model's state dict."""
+    out = {}
+    for variant, concat in (("g", False), ("gc", True)):
+        torch.manual_seed(1234)
+        m = ref_dca.GwcNet(64, use_concat_volume=concat)
+        keys = sorted(m.state_dict().keys())
+        fp = []
+        for k in keys:
+            v = m.state_dict()[k].double().flatten()
+            head = torch.zeros(4, dtype=torch.float64)
+            head[:min(4, v.numel())] = v[:4]
+            fp.append(torch.cat([v.sum().view(1), v.abs().sum().view(1), head]))
+        out[f"{variant}_fp"] = torch.stack(fp)
+    npz("init_fingerprint", **out)
+
+
 def gen_baseline():
     """Baseline gwcnet.GwcNet (3 stacked hourglasses), training branch, from the 1/4-res features."""
     m = ref_gwc.GwcNet(32, use_concat_volume=False)
@@ -336,7 +354,7 @@ def gen_state_dict_keys():
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["volumes", "inject", "attention", "cva", "magg", "hot", "keys", "losses", "baseline", "whole"]
+    which = sys.argv[1:] or ["volumes", "inject", "attention", "cva", "magg", "hot", "keys", "losses", "baseline", "whole", "init"]
     with torch.enable_grad():
         if "volumes" in which: gen_volumes()
         if "inject" in which: gen_context_inject()
@@ -348,3 +366,4 @@ if __name__ == "__main__":
         if "losses" in which: gen_losses()
         if "baseline" in which: gen_baseline()
         if "whole" in which: gen_whole_model()
+        if "init" in which: gen_init()

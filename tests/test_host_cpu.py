@@ -131,3 +131,47 @@ def test_frozen_weights_and_batched_counters_host_logic():
         ops._tls.pending += [n1, n1, n2]
         assert n1.item() == 0
     assert (n1.item(), n2.item()) == (2, 1) and getattr(ops._tls, "pending", None) is None
+
+
+def test_weight_init_is_bit_identical_to_reference():
+    """a10: under the same torch seed a freshly constructed model has the reference's initial weights, bit for bit
+    (gwcnet_dca_g.py:173-185 incl. the ConvTranspose3d / Guidance exceptions and the RNG consumption order);
+    fixture = per-key fingerprints of the reference's own freshly constructed model (oracle/make_golden.py::gen_init)."""
+    import numpy as np
+    import dcanet_amd  # noqa: F401
+    from dcanet_amd.models.gwcnet_dca_g import GwcNet
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "init_fingerprint.npz")))
+    for variant, concat in (("g", False), ("gc", True)):
+        torch.manual_seed(1234)
+        sd = GwcNet(64, use_concat_volume=concat).state_dict()
+        keys = sorted(sd.keys())
+        assert len(keys) == g[f"{variant}_fp"].shape[0]
+        for i, k in enumerate(keys):
+            v = sd[k].double().flatten()
+            head = torch.zeros(4, dtype=torch.float64)
+            head[:min(4, v.numel())] = v[:4]
+            fp = torch.cat([v.sum().view(1), v.abs().sum().view(1), head]).numpy()
+            assert np.array_equal(fp, g[f"{variant}_fp"][i]), f"{variant}: {k} differs from the reference's init"
+
+
+def test_2d_neighbours_match_reference_on_cpu():
+    """the PyTorch 2D modules either side of the path (feature_extraction, Guidance) against the
+    reference's outputs (tests/golden/whole_g_eval.npz) -- they are plain torch modules, so this runs without a GPU."""
+    import json
+    import numpy as np
+    import dcanet_amd  # noqa: F401
+    from dcanet_amd.models.gwcnet_dca_g import GwcNet
+    from oracle import dcanet_oracle as O
+    from oracle.seeded import seeded_tensor
+    with open(os.path.join(ROOT, "tests", "golden", "state_dict_keys.json")) as f:
+        shapes = json.load(f)["g"]
+    m = GwcNet(32, use_concat_volume=False)
+    m.load_state_dict(O.seeded_state_dict({k: tuple(v) for k, v in shapes.items()}), strict=True)
+    m.eval()
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "whole_g_eval.npz")))
+    left = seeded_tensor("whole.left", (1, 3, 64, 128))
+    with torch.no_grad():
+        feat = m.feature_extraction(left)["gwc_feature"]
+        guid = m.guidance(left)["g"]
+    assert (feat[:, ::16] - torch.from_numpy(g["gwc_feature"])).abs().max() < 2e-5
+    assert (guid[:, ::8] - torch.from_numpy(g["guidance"])).abs().max() < 2e-5
