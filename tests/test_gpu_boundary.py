@@ -74,7 +74,8 @@ def test_forward_eval_matches_reference(golden, variant):
     assert pred4.shape == (1, 1, 64, 128) and prob2.shape == (1, 4, 8, 16)
     close(pred4, g["pred4"], name="pred4 (1e-3 abs, north_star)", abs_tol=1e-3)
     close(prob2, g["prob_volume2"], 2e-5, "prob_volume2")
-    assert torch.equal(three[0], pred4) and torch.equal(three[1], prob2), "3-arg call differs from 2-arg call"
+    # (not bitwise: MIOpen may settle on another 2D-conv algorithm after its first-call search)
+    close(three[0], pred4, 1e-5, "3-arg call vs 2-arg call"); close(three[1], prob2, 1e-5, "3-arg call vs 2-arg call")
     L, R = images(True)
     pred4g, prob2g = m(L, R)
     close(pred4g, g["pred4"], name="pred4 (autograd path)", abs_tol=1e-3)
@@ -146,7 +147,7 @@ def test_dataparallel_wrapper_and_prefixed_checkpoint(golden, tmp_path):
     probs, disps = model(L, R)
     close(disps[1], gt["pred4"], name="train pred4 through DataParallel", abs_tol=1e-3)
     close(probs[4], gt["pred2"], 5e-5, "pred2 through DataParallel")
-    (disps[1].mean() + probs[0].square().sum()).backward()
+    (sum(d.mean() for d in disps) + sum(p.square().sum() for p in probs)).backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
 
 
