@@ -198,40 +198,80 @@ def kernel_roofline(device):
     return out
 
 
-def cpu_baseline(m, mode, rows_q=34):
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(m, mode, rows_q=16, iters=3):
     """The CPU oracle (torch CPU restatement of the reference, oracle/dcanet_oracle.py) timed on the host cores
     on a bounded sample: the same workload cropped to `rows_q` of the 136 quarter-res rows (full width, full
-    disparity range), one iteration, scaled by the row fraction."""
+    disparity range), 1 warm-up + `iters` timed iterations, scaled by the row fraction."""
     from oracle import dcanet_oracle as O
-    from dcanet_amd.models.loss import focal_loss, model_loss
-    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()
-          if k.split(".")[0] in ("dres0", "dres1", "cva1", "cva2", "cva3", "classif0", "classif1", "classif2",
-                                 "classif3")}
-    prop = copy.deepcopy(m.prop).cpu()
+    sd0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()
+           if k.split(".")[0] in ("dres0", "dres1", "cva1", "cva2", "cva3", "classif0", "classif1", "classif2",
+                                  "classif3", "prop")}
     fL, fR, guid, gt = make_inputs(1, 0, "cpu", rows_q, W_IMG // 4)
     threads = torch.get_num_threads()
-    t0 = time.time()
-    if mode == "fwd":
-        with torch.no_grad():
-            prop.eval()
-            r = O.hot_path(sd, fL, fR, MAXDISP, False)
-            prop(guid, r["pred4_q"])
-    else:
+
+    def once():
+        sd = {k: v.clone() for k, v in sd0.items()}
+        if mode == "fwd":
+            with torch.no_grad():
+                r = O.hot_path(sd, fL, fR, MAXDISP, False)
+                O.prop(sd, guid, r["pred4_q"], False)
+            return
         for k in sd:
             if sd[k].is_floating_point() and "running" not in k:
                 sd[k].requires_grad_()
-        fL.requires_grad_(); fR.requires_grad_()
-        r = O.hot_path(sd, fL, fR, MAXDISP, True)
-        pred4 = prop.train()(guid, r["pred4_q"])
+        a, b = fL.clone().requires_grad_(), fR.clone().requires_grad_()
+        r = O.hot_path(sd, a, b, MAXDISP, True)
+        pred4 = O.prop(sd, guid, r["pred4_q"], True)
         mask = (gt < MAXDISP) & (gt > 0)
-        loss = focal_loss([r["pred0"], r["pred_dca1"], r["pred_dca2"], r["pred1"], r["pred2"]], gt, MAXDISP, 5.0,
-                          False) + model_loss([r["pred_dca3"], pred4], gt, mask)
+        loss = O.focal_loss([r["pred0"], r["pred_dca1"], r["pred_dca2"], r["pred1"], r["pred2"]], gt, MAXDISP, 5.0,
+                            False) + O.model_loss([r["pred_dca3"], pred4], gt, mask)
         loss.backward()
-    dt = time.time() - t0
+
+    once()                                  # warm-up (allocator, oneDNN primitive caches)
+    times = []
+    for _ in range(iters):
+        t0 = time.time()
+        once()
+        times.append(time.time() - t0)
+    dt = sum(times) / len(times)
     frac = rows_q / (H_IMG // 4)
     return {"value": round(frac / dt, 5), "unit": "cost-volumes/s", "cores": threads, "kind": "port",
-            "sample": f"{mode} on a {4 * rows_q}x{W_IMG} crop ({rows_q}/{H_IMG // 4} of the rows, full width, D={MAXDISP}), "
-                      f"1 iteration, {dt:.1f} s, scaled by the row fraction"}
+            "cpu_model": _cpu_model(), "host_logical_cpus": os.cpu_count(),
+            "sample": f"{mode} on a {4 * rows_q}x{W_IMG} crop ({rows_q}/{H_IMG // 4} of the rows, full width, D={MAXDISP}; "
+                      f"the full frame does not fit the time limit), 1 warm-up + {iters} timed iterations, mean "
+                      f"{dt:.2f} s (min {min(times):.2f}, max {max(times):.2f}), scaled by the row fraction"}
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without torchrun's environment: start N fresh rank processes (one per GPU, RCCL over
+    xGMI) with `python -m torch.distributed.run`, BEFORE this process touches the GPU (a process that has initialised
+    HIP must never exec or fork workers), relay their output (rank 0 prints the JSON line) and return their exit code."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()          # does not initialise the GPU on this image
+    if have < n and os.environ.get("DCA_DIST_BACKEND") != "gloo":
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) are visible (DCA_DIST_BACKEND=gloo lets several ranks share "
+              "one GPU for a rehearsal)", file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -244,7 +284,7 @@ def main():
                          "(fwd+bwd, batch=4) and configs[3] (8 GPUs, batch=32) -- and 1 for the eval forward (configs[1])")
     ap.add_argument("--mode", choices=["fwdbwd", "fwd"], default="fwdbwd")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=34)
+    ap.add_argument("--cpu-rows", type=int, default=16)
     ap.add_argument("--no-prepack", action="store_true", help="fwdbwd mode: re-lay-out each weight in its own launch")
     ap.add_argument("--graph", action="store_true",
                     help="replay the eval hot path (fwd) / the whole training step (fwdbwd, dcanet_amd.graph."
@@ -253,6 +293,8 @@ def main():
     ap.add_argument("--shape", default=None, help="HxWxD of a secondary workload (e.g. 384x1248x192 KITTI, "
                                                   "256x512x64 plumbing); default = BASELINE's 544x960x192")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
 
     if args.batch is None:
         args.batch = 4 if args.mode == "fwdbwd" else 1
@@ -263,7 +305,10 @@ def main():
         args.no_cpu_baseline = True
     from dcanet_amd.parallel import FlatGradBucket, init_from_env
     rank, local, world = init_from_env()
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}")
+    if world > 1 and dist.get_world_size() != args.gpus:
+        raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, expected {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
     device = torch.device("cuda", local % torch.cuda.device_count())
