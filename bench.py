@@ -140,12 +140,6 @@ def kernel_roofline(device):
         if ops.CONV_X3:
             cases.append(("conv3_bf16x3_kernel (3x3x3 32->32 @1/4 res; fp32 via exact 3-way bf16 split, 6 bf16 MFMA "
                           "products per fp32 product)", "conv3_bf16x3", PEAK_BF16_MFMA_TFLOPS / 6.0, run_x3))
-        if ops.WINOGRAD:
-            ug = torch.empty((48, 32, 32), device=device)
-            ops._chk(lib.dca_conv3d_wino_prep_weight(ops._ptr(wgt), ops._ptr(ug), 32, 32, 32, 0, 0, 32, 0,
-                                                     ops._stream()), "wino prep")
-            cases.append(("wino_conv3_kernel F(2x2,3x3)xD (3x3x3 32->32 @1/4 res, algorithmic FLOPs)", None,
-                          PEAK_FP32_MFMA_TFLOPS, lambda: ops.conv3d_wino_prepared(x, ug, 32, 32, 32)))
         cases.append(("conv3_mfma_kernel<S1,Cout32,CK8,tile 4x8x16> (3x3x3 32->32 @1/4 res, fp32 MFMA)", "conv3_mfma",
                       PEAK_FP32_MFMA_TFLOPS, lambda: ops.conv3d_prepared(x, wt, 32, cpad, 32, 3, 1, False)))
         def run_wgrad(x3):

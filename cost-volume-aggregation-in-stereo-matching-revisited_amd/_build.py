@@ -1,34 +1,59 @@
-"""Builds libdca_hip.so (hand-written HIP kernels, gfx950 only) in-tree with hipcc."""
+"""Builds libdca_hip.so (hand-written HIP kernels, gfx950 only) in-tree with hipcc: one object per .hip source
+(compiled in parallel, re-compiled only when the source or a header changed), then one link."""
+import concurrent.futures
 import os
 import shutil
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libdca_hip.so")
-SOURCES = ["conv3d_mfma.hip", "conv3d_winograd.hip", "conv3d_bf16x3.hip", "prep_many.hip", "conv3d_wgrad.hip", "conv3d_wgrad_bf16x3.hip", "conv3d_c1.hip", "volume.hip", "up_softargmin.hip", "pointwise.hip", "context_attention.hip"]
+HEADER = os.path.join(HERE, "..", "include", "dca_hip.h")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+
+
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _headers():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [HEADER]
+
+
+def _newer(path, than):
+    return (not os.path.exists(than)) or os.path.getmtime(path) > os.path.getmtime(than)
 
 
 def _stale() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "dca_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    deps = [os.path.join(CSRC, f) for f in sources()] + _headers()
+    return any(_newer(d, LIB) for d in deps if os.path.exists(d))
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 -shared; cross-compiles without a GPU."""
+    """hipcc --offload-arch=gfx950 -c per source, then -shared; cross-compiles without a GPU."""
     if not force and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True, cwd=CSRC)
+    os.makedirs(OBJ, exist_ok=True)
+    jobs = []
+    for src in sources():
+        s, o = os.path.join(CSRC, src), os.path.join(OBJ, src[:-4] + ".o")
+        if force or _newer(s, o) or any(_newer(h, o) for h in _headers() if os.path.exists(h)):
+            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+        list(ex.map(run, jobs))
+    objs = [os.path.join(OBJ, s[:-4] + ".o") for s in sources()]
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -8,8 +8,11 @@ LIB_PATH = os.path.join(HERE, "libdca_hip.so")
 
 _p, _i, _l, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double
 
+ABI_VERSION = 2   # == DCA_ABI_VERSION of include/dca_hip.h
+
 # name -> (restype, argtypes); mirrors include/dca_hip.h one to one
 SIGNATURES = {
+    "dca_abi_version": (_i, []),
     "dca_gwc_volume_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "dca_gwc_volume_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "dca_concat_volume_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
@@ -20,8 +23,6 @@ SIGNATURES = {
     "dca_up_softargmin_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "dca_conv3d_prep_weight": (_i, [_p, _p] + [_i] * 9 + [_p]),
     "dca_conv3d_forward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _f] + [_i] * 16 + [_p]),
-    "dca_conv3d_wino_prep_weight": (_i, [_p, _p] + [_i] * 7 + [_p]),
-    "dca_conv3d_wino_forward": (_i, [_p] * 7 + [_f] + [_i] * 9 + [_p]),
     "dca_conv3d_prep_many": (_i, [_p, _i, _p]),
     "dca_conv3d_x3_weight_bytes": (_l, [_i, _i]),
     "dca_conv3d_x3_prep_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
@@ -46,6 +47,11 @@ SIGNATURES = {
     "dca_context_inject_bwd": (_i, [_p] * 12 + [_i, _i, _i, _l, _p]),
     "dca_disp_attention_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _l, _p]),
     "dca_disp_attention_bwd": (_i, [_p] * 7 + [_i, _i, _i, _l, _p]),
+    "dca_convex_up4_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "dca_convex_up4_bwd": (_i, [_p] * 6 + [_i, _i, _i, _p]),
+    "dca_focal_loss_workspace": (_l, [_i, _i, _l]),
+    "dca_focal_loss_fwd": (_i, [_p, _p, _i, _p, _p, _p, _i, _i, _l, _f, _p]),
+    "dca_focal_loss_bwd": (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _l, _f, _p]),
 }
 
 _lib = None
@@ -64,5 +70,9 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing -> loud
         fn.restype, fn.argtypes = res, args
+    got = lib.dca_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} was built from another version of include/dca_hip.h (ABI {got}, this package "
+                           f"binds ABI {ABI_VERSION}): rebuild it with `python -c 'import __graft_entry__ as g; g.build()'`")
     _lib = lib
     return lib

@@ -1,65 +1,100 @@
-"""Mirror of the reference's models/loss.py for the two losses main_dca.py:132-133 uses.
+"""Mirror of the reference's models/loss.py for the symbols its scripts import: `focal_loss`, `model_loss`
+(main_dca.py:14,132-133) and `StereoFocalLoss` (train_kitti.py:16,101-110).
 
-Host-side PyTorch code (works on any device): it sits AFTER the hot path and is small
-next to it.  Vectorised restatement of StereoFocalLoss.loss_per_level / LaplaceDisp2Prob (loss.py:117-128,
-206-240) and model_loss (loss.py:6-14); quirks of the reference are reproduced, not fixed (the estimates
-handed in are already softmax outputs and get log_softmax-ed again; the mean runs over all pixels)."""
+The stereo focal loss runs as ONE HIP kernel per direction for all levels of a resolution (csrc/heads2d.hip: log-softmax,
+Laplace target, focal weight, masks and the mean fused; the reference materialises five (B,48,h,w) temporaries per
+level).  Quirks of the reference are reproduced, not fixed: the estimates handed in by GwcNet are already softmax
+outputs and get log_softmax-ed again; the mean runs over all pixels, valid or not.  Like every kernel of this package
+the focal loss needs ROCm tensors: there is no CPU fallback."""
 import torch
 import torch.nn.functional as F
+
+from ._bootstrap import ensure as _ensure
+
+ops = _ensure().ops
 
 
 def model_loss(disp_ests, disp_gt, mask):
     """reference loss.py:6-14: 1.8*SmoothL1(est0[mask]) + 2.1*SmoothL1(est1[mask]), mean over the masked pixels.
 
-    Written as sum(mask * loss) / count(mask) instead of boolean indexing: same value and gradient (0/0 = NaN for an
-    empty mask, like the mean of an empty selection), but no `nonzero` -- boolean indexing synchronises the host with
-    the GPU in the middle of the training step, and everything after it is launched into an empty queue."""
+    Written with torch.where instead of boolean indexing: same value and gradient for finite inputs, no `nonzero` (a
+    host<->GPU sync in the middle of the training step), and -- unlike a multiplication by the mask -- a non-finite
+    estimate or ground truth at a masked-OUT pixel stays out of the sum, as with the reference's `est[mask]`.  An empty
+    mask gives 0/0 = NaN like the mean of an empty selection.
+
+    Data parallel note: every rank takes its own masked mean and the gradients are averaged over ranks; that equals
+    nn.DataParallel's global masked mean only when all ranks hold the same number of valid pixels (true for dense
+    ground truth).  `model_loss_parts` returns (numerator, count) for callers that all-reduce both."""
+    num, count = model_loss_parts(disp_ests, disp_gt, mask)
+    return num / count
+
+
+def model_loss_parts(disp_ests, disp_gt, mask):
     weights = [1.8, 2.1]
     assert len(weights) == len(disp_ests)
-    m = mask.to(disp_gt.dtype)
-    count = m.sum()
-    return sum(w * (F.smooth_l1_loss(est, disp_gt, reduction="none") * m).sum() / count
-               for est, w in zip(disp_ests, weights))
+    zero = torch.zeros((), dtype=disp_gt.dtype, device=disp_gt.device)
+    num = sum(w * torch.where(mask, F.smooth_l1_loss(est, disp_gt, reduction="none"), zero).sum()
+              for est, w in zip(disp_ests, weights))
+    return num, mask.sum().to(disp_gt.dtype)
 
 
-def _focal_target(gt, H, W, maxdisp, focal_coefficient, sparse, dtype, device):
-    """everything of a level that does not depend on the estimate: the Laplace target distribution of the (pooled)
-    ground truth, times the focal weight, times the validity mask (reference loss.py:117-128, 206-240)"""
-    gt = gt.view(gt.shape[0], 1, gt.shape[-2], gt.shape[-1]) if gt.dim() != 4 else gt
-    scale = 1.0
-    sgt = gt
-    if gt.shape[-2] != H or gt.shape[-1] != W:
-        scale = gt.shape[-1] / (W * 1.0)
-        pool = F.adaptive_max_pool2d if sparse else F.adaptive_avg_pool2d
-        sgt = pool(gt / scale, (H, W))
-    nd = int(maxdisp / scale)
-    mask = ((sgt > 0) & (sgt < nd)).to(dtype)
-    mgt = sgt * mask
-    inner = ((mgt > 0) & (mgt < nd - 1)).to(dtype)          # Disp2Prob.getProb, loss.py:87-90
-    index = torch.arange(0, nd, dtype=dtype, device=device).view(1, nd, 1, 1)
-    prob = F.softmax(-torch.abs(index - mgt * inner), dim=1) * inner + 1e-40
-    prob = prob * (mask.sum() >= 1.0).to(dtype)            # "no valid point" -> zero target (loss.py:224-227)
-    weight = (1.0 - prob).pow(-focal_coefficient)
-    return prob, weight, mask
+def _pooled_gt(gt, H, W, sparse):
+    """loss_per_level's ground-truth scaling (loss.py:208-215): gt / scale pooled to the level's resolution;
+    scale = W_gt / W.  Returns (pooled gt (B,1,H,W), scale)."""
+    if gt.dim() == 2:
+        gt = gt.view(1, 1, *gt.shape)
+    elif gt.dim() == 3:
+        gt = gt.view(gt.shape[0], 1, gt.shape[1], gt.shape[2])
+    if gt.shape[-2] == H and gt.shape[-1] == W:
+        return gt, 1.0
+    scale = gt.shape[-1] / (W * 1.0)
+    pool = F.adaptive_max_pool2d if sparse else F.adaptive_avg_pool2d
+    return pool(gt / scale, (H, W)), scale
 
 
-def _focal_level(est, target):
-    prob, weight, mask = target
-    logp = F.log_softmax(est, dim=1)
-    return -((prob * logp) * weight * mask).sum(dim=1, keepdim=True).mean()
+class StereoFocalLoss(object):
+    """reference loss.py:168-247, same constructor and call signature.  `variance` and `dilation` are accepted and, as in
+    the reference's LaplaceDisp2Prob.calProb (loss.py:122-126), not used."""
+
+    def __init__(self, max_disp=192, start_disp=0, dilation=1, weights=None, focal_coefficient=0.0, sparse=False):
+        if start_disp != 0:
+            raise NotImplementedError("StereoFocalLoss: only start_disp = 0 (every call site of the reference)")
+        self.max_disp = max_disp
+        self.start_disp = start_disp
+        self.dilation = dilation
+        self.weights = weights
+        self.focal_coefficient = focal_coefficient
+        self.sparse = sparse
+        self.scale_func = F.adaptive_max_pool2d if sparse else F.adaptive_avg_pool2d
+
+    def loss_levels(self, ests, weights, gtDisp):
+        """sum_l weights[l] * loss_per_level(ests[l]) for estimates of one resolution: one kernel launch."""
+        N, C, H, W = ests[0].shape
+        gt, scale = _pooled_gt(gtDisp, H, W, self.sparse)
+        if int(self.max_disp / scale) != C:
+            raise RuntimeError(f"StereoFocalLoss: the estimate has {C} disparity bins but max_disp / scale = "
+                               f"{int(self.max_disp / scale)} (the reference's broadcast would fail as well)")
+        return ops.focal_loss_levels(list(ests), gt, list(weights), self.focal_coefficient)
+
+    def loss_per_level(self, estCost, gtDisp, variance=1.0, dilation=1):
+        return self.loss_levels([estCost], [1.0], gtDisp)
+
+    def __call__(self, estCost, gtDisp, variance):
+        return self.loss_per_level(estCost, gtDisp, variance)
 
 
 def focal_loss(disp_ests, disp_gt, maxdisp, focal_coefficient, sparse):
-    """reference loss.py:16-24 (weights [0.5,0.7,1.0,1.2,1.5], silently truncating like zip does).  The target side of
-    a level depends only on the ground truth and the level's resolution, so levels of equal resolution (all five in
-    DCANet) share one target instead of re-pooling / re-softmaxing the ground truth five times."""
+    """reference loss.py:16-24 (weights [0.5,0.7,1.0,1.2,1.5], silently truncating like zip does).  Levels of equal shape
+    (all five in DCANet) go through one kernel launch that computes the ground-truth side once."""
     weights = [0.5, 0.7, 1.0, 1.2, 1.5]
-    targets = {}
-    total = 0
+    ev = StereoFocalLoss(max_disp=maxdisp, focal_coefficient=focal_coefficient, sparse=sparse)
+    groups = {}
     for est, w in zip(disp_ests, weights):
-        key = (est.shape[-2], est.shape[-1], est.dtype, est.device)
-        if key not in targets:
-            targets[key] = _focal_target(disp_gt, est.shape[-2], est.shape[-1], maxdisp, focal_coefficient, sparse,
-                                         est.dtype, est.device)
-        total = total + w * _focal_level(est, targets[key])
+        groups.setdefault(tuple(est.shape), ([], []))
+        groups[tuple(est.shape)][0].append(est)
+        groups[tuple(est.shape)][1].append(w)
+    total = 0
+    for ests, ws in groups.values():
+        for i in range(0, len(ests), 8):
+            total = total + ev.loss_levels(ests[i:i + 8], ws[i:i + 8], disp_gt)
     return total

@@ -180,7 +180,8 @@ class Guidance(nn.Module):
 
 class PropgationNet_4x(nn.Module):
     """reference models/submodule.py:357-373 (identical copy models/gwcnet_dca_g.py:108-124):
-    9-neighbour convex x4 up-sampling of the 1/4-res disparity, values scaled by 4."""
+    9-neighbour convex x4 up-sampling of the 1/4-res disparity, values scaled by 4.  The mask conv stays on
+    PyTorch-ROCm (2D); everything after it is one fused kernel."""
 
     def __init__(self, base_channels):
         super().__init__()
@@ -190,8 +191,5 @@ class PropgationNet_4x(nn.Module):
                                             dilation=(1, 1), bias=False))
 
     def forward(self, guidance, disp):
-        b, c, h, w = disp.shape
-        nb = F.unfold(4 * disp, [3, 3], padding=1).view(b, 1, 9, 1, 1, h, w)
-        mask = F.softmax(self.conv(guidance).view(b, 1, 9, 4, 4, h, w), dim=2)
-        up = torch.sum(mask * nb, dim=2).permute(0, 1, 4, 2, 5, 3)
-        return up.reshape(b, 1, 4 * h, 4 * w)
+        # unfold(4*disp) . softmax_9(mask) . sum . pixel-shuffle as one HIP kernel (csrc/heads2d.hip)
+        return ops.convex_upsample4(self.conv(guidance), disp)

@@ -209,12 +209,6 @@ def _round_up(a, m):
     return (a + m - 1) // m * m
 
 
-# Experimental Winograd F(2x2,3x3) path for the 3x3x3 stride-1 convolutions with <= 32 output channels.  Correct
-# (tests run it) but NOT faster than the direct MFMA kernel on MI355X (0.86 ms vs 0.86 ms for 32->32 at 48x136x240:
-# profiles/README.md), so it is opt-in: DCA_WINOGRAD=1.
-WINOGRAD = os.environ.get("DCA_WINOGRAD", "0") == "1"
-
-
 # 3x3x3 stride-1 convolutions run on the bf16 matrix pipe with the exact three-way bf16 split of both operands
 # ("bf16x3", conv3d_bf16x3.hip): fp32-grade accuracy (measured error vs fp64 slightly BELOW the fp32 MFMA kernel's)
 # at 1.3-1.75x the speed on every shape the networks use, 1/4 to 1/16 resolution (tools/x3_vs_fp32.py).
@@ -275,15 +269,6 @@ def _conv_sliced(x, x2, w_src, A, B, K, src_ab, flip, ksize, stride, transposed,
     C1 = x.shape[1]
     width = _slice_width(ksize, stride, transposed, B)
     lib = _L()
-    if WINOGRAD and ksize == 3 and stride == 1 and not transposed and B <= 32 and x2 is None:
-        Apad = _round_up(A, 4)
-        ug = torch.empty((48, Apad, 32), device=x.device, dtype=torch.float32)
-        _chk(lib.dca_conv3d_wino_prep_weight(_ptr(w_src), _ptr(ug), A, B, Apad, int(src_ab), int(flip), B, 0,
-                                             _stream()), "dca_conv3d_wino_prep_weight")
-        _chk(lib.dca_conv3d_wino_forward(_ptr(x), _ptr(ug), _ptr(y), _ptr(scale), _ptr(shift), _ptr(res_pre),
-                                         _ptr(res_post), float(slope), N, A, B, Apad, B, 0, Di, Hi, Wi, _stream()),
-             "dca_conv3d_wino_forward")
-        return y
     if _x3_eligible(x, x2, ksize, stride, transposed, A, B):
         def build_x3():
             w3 = torch.empty((lib.dca_conv3d_x3_weight_bytes(A, B) // 2,), device=x.device, dtype=torch.int16)
@@ -314,16 +299,6 @@ def conv3d_prepared(x, wt, A, Apad, B, ksize, stride, transposed):
     _chk(_L().dca_conv3d_forward(_ptr(x), None, _ptr(wt), _ptr(y), None, None, None, None, 1.0, N, A, A, B, Apad, B, 0,
                                  Di, Hi, Wi, Do, Ho, Wo, ksize, stride, int(transposed), _stream()),
          "dca_conv3d_forward")
-    return y
-
-
-def conv3d_wino_prepared(x, ug, A, Apad, B):
-    """single Winograd launch with an already transformed weight (bench.py)"""
-    N = x.shape[0]
-    D, H, W = x.shape[2:]
-    y = torch.empty((N, B, D, H, W), device=x.device, dtype=torch.float32)
-    _chk(_L().dca_conv3d_wino_forward(_ptr(x), _ptr(ug), _ptr(y), None, None, None, None, 1.0, N, A, B, Apad, B, 0, D, H,
-                                      W, _stream()), "dca_conv3d_wino_forward")
     return y
 
 
@@ -847,3 +822,87 @@ def context_inject(x, preds):
 
 def disparity_attention(q, k, v):
     return _DispAttention.apply(q, k, v)
+
+
+# ------------------------------------------------------------------------------------------------
+# convex x4 up-sampling and the stereo focal loss (csrc/heads2d.hip)
+# ------------------------------------------------------------------------------------------------
+class _ConvexUp4(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mask_logits, disp):
+        mask_logits, disp = _req(mask_logits, "convex_upsample4.mask"), _req(disp, "convex_upsample4.disp")
+        B, C, h, w = mask_logits.shape
+        if C != 144 or tuple(disp.shape) != (B, 1, h, w):
+            raise RuntimeError(f"convex_upsample4: expected mask (B,144,h,w) and disp (B,1,h,w), got "
+                               f"{tuple(mask_logits.shape)} and {tuple(disp.shape)}")
+        up = torch.empty((B, 1, 4 * h, 4 * w), device=disp.device, dtype=torch.float32)
+        with torch.cuda.device_of(disp):
+            _chk(_L().dca_convex_up4_fwd(_ptr(mask_logits), _ptr(disp), _ptr(up), B, h, w, _stream()),
+                 "dca_convex_up4_fwd")
+        ctx.save_for_backward(mask_logits, disp)
+        return up
+
+    @staticmethod
+    def backward(ctx, gup):
+        mask_logits, disp = ctx.saved_tensors
+        gup = _req(gup, "convex_upsample4.backward")
+        B, _, h, w = mask_logits.shape
+        gl, gd = torch.empty_like(mask_logits), torch.empty_like(disp)
+        wk = torch.empty((B, 9, h, w), device=disp.device, dtype=torch.float32)
+        with torch.cuda.device_of(disp):
+            _chk(_L().dca_convex_up4_bwd(_ptr(mask_logits), _ptr(disp), _ptr(gup), _ptr(gl), _ptr(gd), _ptr(wk), B, h, w,
+                                         _stream()), "dca_convex_up4_bwd")
+        return gl, gd
+
+
+def convex_upsample4(mask_logits, disp):
+    """PropgationNet_4x.forward after its conv (models/submodule.py:366-373): (B,144,h,w), (B,1,h,w) -> (B,1,4h,4w)."""
+    return _ConvexUp4.apply(mask_logits, disp)
+
+
+class _FocalLevels(torch.autograd.Function):
+    """sum_l w_l * StereoFocalLoss.loss_per_level(est_l, gt) for estimates of ONE resolution; `gt` is already pooled."""
+
+    @staticmethod
+    def forward(ctx, gt, coef, weights, *ests):
+        ests = [_req(e, "focal_loss.est") for e in ests]
+        gt = _req(gt, "focal_loss.gt")
+        B, K = ests[0].shape[0], ests[0].shape[1]
+        HW = ests[0][0, 0].numel()
+        n = len(ests)
+        if n > 8 or K > 256 or K < 2 or any(e.shape != ests[0].shape for e in ests) or gt.numel() != B * HW:
+            raise RuntimeError("focal_loss: at most 8 equally shaped (B,K<=256,H,W) estimates per call and a ground truth "
+                               "pooled to (B,1,H,W)")
+        lib = _L()
+        work = torch.empty((lib.dca_focal_loss_workspace(n, B, HW),), device=gt.device, dtype=torch.float64)
+        out = torch.empty((n + 1,), device=gt.device, dtype=torch.float32)
+        eptr = (ctypes.c_void_p * n)(*[e.data_ptr() for e in ests])
+        wts = (ctypes.c_float * n)(*[float(w) for w in weights])
+        with torch.cuda.device_of(gt):
+            _chk(lib.dca_focal_loss_fwd(eptr, wts, n, _ptr(gt), _ptr(work), _ptr(out), B, K, HW, float(coef), _stream()),
+                 "dca_focal_loss_fwd")
+        ctx.save_for_backward(gt, work, *ests)
+        ctx.meta = (float(coef), [float(w) for w in weights])
+        return out[n]
+
+    @staticmethod
+    def backward(ctx, gloss):
+        gt, work, *ests = ctx.saved_tensors
+        coef, weights = ctx.meta
+        n = len(ests)
+        B, K = ests[0].shape[0], ests[0].shape[1]
+        HW = ests[0][0, 0].numel()
+        gloss = _req(gloss.reshape(1), "focal_loss.backward")
+        gests = [torch.empty_like(e) for e in ests]
+        eptr = (ctypes.c_void_p * n)(*[e.data_ptr() for e in ests])
+        gptr = (ctypes.c_void_p * n)(*[g.data_ptr() for g in gests])
+        wts = (ctypes.c_float * n)(*weights)
+        with torch.cuda.device_of(gt):
+            _chk(_L().dca_focal_loss_bwd(eptr, gptr, wts, n, _ptr(gt), _ptr(work), _ptr(gloss), B, K, HW, coef, _stream()),
+                 "dca_focal_loss_bwd")
+        return (None, None, None) + tuple(gests)
+
+
+def focal_loss_levels(ests, gt_pooled, weights, focal_coefficient):
+    """Weighted stereo focal loss (models/loss.py:206-240) of several estimates that share one resolution."""
+    return _FocalLevels.apply(gt_pooled, float(focal_coefficient), tuple(float(w) for w in weights), *ests)

@@ -21,6 +21,11 @@
 extern "C" {
 #endif
 
+/* Bumped whenever an argument list below changes; the ctypes loader (_lib.py) refuses a library built from another
+ * version of this header. */
+#define DCA_ABI_VERSION 2
+int dca_abi_version(void);
+
 /* ---- cost volumes ------------------------------------------------------------------------------
  * build_gwc_volume(refimg_fea, targetimg_fea, maxdisp, num_groups)  models/submodule.py:157-167
  * (groupwise_correlation, submodule.py:148-154).  ref,tgt: (B,C,H,W); vol: (B,G,maxdisp,H,W). */
@@ -90,16 +95,6 @@ int dca_conv3d_forward(const float* x, const float* x2, const float* wt, float* 
 long dca_conv3d_wgrad_workspace(int N, int Cx, int Cy, int Do, int Ho, int Wo, int ksize, int stride);
 int dca_conv3d_wgrad(const float* x, const float* dy, float* part, float* dw, int N, int Cx, int Cy, int Di, int Hi,
                      int Wi, int Do, int Ho, int Wo, int ksize, int stride, long s_cy, long s_cx, hipStream_t stream);
-
-/* Winograd F(2x2,3x3) over (H,W), direct over D, for ksize 3 / stride 1 / Cout <= 32 (2.25x fewer matrix FLOPs, fp32).
- * dca_conv3d_wino_prep_weight lays the weight out as ug[(xi*3+kd)][Apad][32] = G g G^T (A, B, src_ab, flip, Btotal,
- * b_off as in dca_conv3d_prep_weight; Apad = A rounded up to 4).  dca_conv3d_wino_forward is a drop-in for
- * dca_conv3d_forward on those shapes (same epilogue and channel-offset semantics); y and ug must be 16-byte aligned. */
-int dca_conv3d_wino_prep_weight(const float* w, float* ug, int A, int B, int Apad, int src_ab, int flip, int Btotal,
-                                int b_off, hipStream_t stream);
-int dca_conv3d_wino_forward(const float* x, const float* ug, float* y, const float* scale, const float* shift,
-                            const float* res_pre, const float* res_post, float slope, int N, int Cin, int Cout,
-                            int CinPad, int CoutTotal, int co_off, int D, int H, int W, hipStream_t stream);
 
 /* Batched weight re-layout: ONE launch for n descriptors of dca_conv3d_prep_weight (kind 0) / dca_conv3d_x3_prep_weight
  * (kind 1) work (prep_many.hip) -- a training step re-packs every conv weight after the optimizer update, and ~130
@@ -189,6 +184,28 @@ int dca_disp_attention_fwd(const float* q, const float* k, const float* v, float
                            hipStream_t stream);
 int dca_disp_attention_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq, float* dk,
                            float* dv, int B, int C, int n, long HW, hipStream_t stream);
+
+/* ---- the steps right after the path ------------------------------------------------------
+ * Convex x4 up-sampling, PropgationNet_4x.forward after its conv (models/submodule.py:366-373, copy
+ * models/gwcnet_dca_g.py:114-124): mask_logits (B,144,h,w) with channel = k*16 + i*4 + j, disp (B,1,h,w) in 1/4-res
+ * pixels -> up (B,1,4h,4w) = sum_k softmax_k(mask)[k,i,j] * 4*disp[3x3 zero-padded neighbour k].
+ * bwd: glogits (B,144,h,w), gdisp (B,1,h,w); wk = B*9*h*w floats of scratch. */
+int dca_convex_up4_fwd(const float* mask_logits, const float* disp, float* up, int B, int h, int w, hipStream_t stream);
+int dca_convex_up4_bwd(const float* mask_logits, const float* disp, const float* gup, float* glogits, float* gdisp,
+                       float* wk, int B, int h, int w, hipStream_t stream);
+
+/* Stereo focal loss, StereoFocalLoss.loss_per_level + LaplaceDisp2Prob (models/loss.py:206-240, 60-128), for `nlev`
+ * estimates of equal shape (B,K,HW) that share one ground truth gt (B,HW) ALREADY scaled/pooled to that resolution
+ * (loss.py:210-215 stays on the host: one adaptive pooling per resolution).  ests / gests / weights are HOST arrays of
+ * nlev (<= 8) device pointers / floats.  out: nlev+1 floats = the per-level losses (un-weighted, loss.py:238) and
+ * sum_l weights[l]*loss_l (focal_loss, loss.py:16-24).  K <= 256.  work: dca_focal_loss_workspace(...) doubles, must be
+ * handed unchanged to the backward call, which writes gests[l] = d(out[nlev]) / d(ests[l]) * gloss[0]. */
+long dca_focal_loss_workspace(int nlev, int B, long HW);
+int dca_focal_loss_fwd(const float* const* ests, const float* weights, int nlev, const float* gt, double* work,
+                       float* out, int B, int K, long HW, float focal_coefficient, hipStream_t stream);
+int dca_focal_loss_bwd(const float* const* ests, float* const* gests, const float* weights, int nlev, const float* gt,
+                       const double* work, const float* gloss, int B, int K, long HW, float focal_coefficient,
+                       hipStream_t stream);
 
 #ifdef __cplusplus
 }

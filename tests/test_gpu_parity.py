@@ -282,24 +282,6 @@ def test_conv3d_bf16x3_fused_epilogue(monkeypatch):
     close(y, ref, 1e-5, "fused")
 
 
-@pytest.mark.parametrize("case", [(40, 32, (4, 6, 10), 2), (32, 32, (5, 10, 68), 1), (32, 27, (3, 9, 36), 1), (64, 32, (4, 8, 40), 1)])
-def test_conv3d_winograd_path(case, monkeypatch):
-    """the opt-in Winograd F(2x2,3x3)xD kernel (forward and, through autograd, stride-1 backward-data)"""
-    _, ops = _mods()
-    monkeypatch.setattr(ops, "WINOGRAD", True)
-    cin, cout, dims, N = case
-    x = seeded_tensor(f"wg.x{case}", (N, cin) + dims)
-    w = seeded_tensor(f"wg.w{case}", (cout, cin, 3, 3, 3)) * (1.0 / (cin * 27) ** 0.5)
-    xc, wc = cpu_leaf(x), cpu_leaf(w)
-    yr = F.conv3d(xc, wc, None, 1, 1)
-    gy = seeded_tensor(f"wg.g{case}", yr.shape)
-    gxr, gwr = torch.autograd.grad((yr * gy).sum(), [xc, wc])
-    xg, wg = gpu(x, True), gpu(w, True)
-    y = ops.conv3d(xg, wg, 1, False)
-    gx, gw = torch.autograd.grad((y * gy.to(DEV)).sum(), [xg, wg])
-    close(y, yr, 1e-5, "fwd"); close(gx, gxr, 1e-5, "dx"); close_l2(gw, gwr, 1e-5, "dw")
-
-
 def test_frozen_weights_cache_is_exact_and_scoped():
     """ops.frozen_weights(): cached weight re-layouts / BN folds give bit-identical results, are reused inside the
     context, and are dropped (weights may change again) outside it"""
