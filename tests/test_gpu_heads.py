@@ -107,7 +107,5 @@ def test_training_losses_full_size_properties():
     gr = torch.autograd.grad(fl, ests)
     for g_ in gr:
         assert g_.sum(1).abs().max().item() < 1e-9 * 48 + 1e-10
-    same = torch.autograd.grad(focal_loss([ests[0].detach().requires_grad_()] * 1 + [e.detach() for e in ests[1:]], gt,
-                                          192, 5.0, False), [])  if False else None  # noqa: F841
     r = gr[4].norm() / gr[0].norm()
     assert 0.5 < r.item() < 20.0
