@@ -194,3 +194,34 @@ def test_2d_neighbours_match_reference_on_cpu():
         guid = m.guidance(left)["g"]
     assert (feat[:, ::16] - torch.from_numpy(g["gwc_feature"])).abs().max() < 2e-5
     assert (guid[:, ::8] - torch.from_numpy(g["guidance"])).abs().max() < 2e-5
+
+
+def test_kitti_wrapper_host_logic(tmp_path):
+    """dcanet_amd.inference: my_img.py:47-110's normalisation / padding / cropping / 16-bit PNG, against an independent
+    plain-numpy restatement of those lines."""
+    import numpy as np
+    from PIL import Image
+    from dcanet_amd.inference import crop_back, disparity_png, normalize_pair, pad_or_crop
+    rng = np.random.default_rng(3)
+    left = rng.integers(0, 256, (37, 121, 3), dtype=np.uint8)
+    right = rng.integers(0, 256, (37, 121, 3), dtype=np.uint8)
+    t = normalize_pair(left, right)
+    assert t.shape == (6, 37, 121) and t.dtype == np.float32
+    for i, img in enumerate((left, right)):
+        for c in range(3):
+            want = ((img[:, :, c] - img[:, :, c].mean()) / img[:, :, c].std()).astype("float32")
+            assert np.array_equal(t[3 * i + c], want)
+            assert abs(float(t[3 * i + c].mean())) < 1e-5 and abs(float(t[3 * i + c].std()) - 1) < 1e-4
+    L, R, h, w = pad_or_crop(t, 48, 128)          # smaller than the frame: bottom-left corner, zeros top / right
+    assert (h, w) == (37, 121) and L.shape == R.shape == (1, 3, 48, 128)
+    assert np.array_equal(L[0, :, 11:, :121].numpy(), t[0:3]) and np.array_equal(R[0, :, 11:, :121].numpy(), t[3:6])
+    assert float(L[0, :, :11].abs().max()) == 0 and float(L[0, :, :, 121:].abs().max()) == 0
+    disp = rng.random((48, 128)).astype("float32") * 100
+    assert np.array_equal(crop_back(disp, h, w, 48, 128), disp[11:, :121])
+    L2, R2, h2, w2 = pad_or_crop(t, 32, 64)       # larger than the frame: vertically centred crop from column 0
+    assert (h2, w2) == (37, 121) and np.array_equal(L2[0].numpy(), t[0:3, 2:34, 0:64])
+    assert crop_back(disp, h2, w2, 32, 64) is disp
+    png = str(tmp_path / "000000_10.png")
+    disparity_png(png, disp)
+    back = np.asarray(Image.open(png))
+    assert back.dtype == np.uint16 and np.array_equal(back, (disp * 256).astype("uint16"))
