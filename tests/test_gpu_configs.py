@@ -125,7 +125,7 @@ def test_train_step_d192_row_crop_all_gradients(variant, capsys):
     errs = sorted(e for _, e, _ in rows)
     # gates: see test_gpu_parity.py::test_golden_hot_path for why end-to-end train-mode gradients are gated on rel-L2
     assert errs[len(errs) // 2] <= 5e-3, f"median per-tensor gradient error {errs[len(errs) // 2]:.3e}"
-    bad = [(n, e) for n, e, nr in rows if e > 3e-2 and nr > 1e-6]
+    bad = [(n, e) for n, e, nr in rows if e > 1.5e-2 and nr > 1e-6]   # measured max 4.8e-3 (G), 6.9e-3 (GC)
     assert not bad, bad
 
 
@@ -151,5 +151,5 @@ def test_wgrad_full_size_batch4_is_deterministic_and_additive():
         g4a, g4b, g1 = wg(x4, dy4), wg(x4, dy4), wg(x1, dy1)
         assert torch.equal(g4a, g4b), f"{name}: two runs differ"
         err = ((g4a - 4 * g1).norm() / (4 * g1).norm()).item()
-        assert err <= 2e-6, f"{name}: batch-4 gradient is not 4x the single-sample gradient (rel {err:.2e})"
+        assert err <= 2e-5, f"{name}: batch-4 gradient is not 4x the single-sample gradient (rel {err:.2e})"
         del x4, dy4
