@@ -906,3 +906,56 @@ class _FocalLevels(torch.autograd.Function):
 def focal_loss_levels(ests, gt_pooled, weights, focal_coefficient):
     """Weighted stereo focal loss (models/loss.py:206-240) of several estimates that share one resolution."""
     return _FocalLevels.apply(gt_pooled, float(focal_coefficient), tuple(float(w) for w in weights), *ests)
+
+
+# ------------------------------------------------------------------------------------------------
+# Reduced-precision inference (BASELINE configs 2 / 5): bf16 or fp16 storage, one MFMA product, fp32 accumulation
+# ------------------------------------------------------------------------------------------------
+LP_DTYPES = {torch.bfloat16: 1, torch.float16: 2}      # DCA_BF16 / DCA_FP16 of include/dca_hip.h
+
+
+def _req_lp(t, name, lp):
+    """contiguous ROCm tensor that is either fp32 or the 2-byte type `lp`"""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name}: the DCANet hot path runs only as HIP kernels on a ROCm device; there is no CPU fallback")
+    if t.dtype not in (torch.float32, lp):
+        raise RuntimeError(f"{name}: expected float32 or {lp}, got {t.dtype}")
+    t = t.contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone(memory_format=torch.contiguous_format)
+    return t
+
+
+def conv3d_lp(x, weight, lp, scale=None, shift=None, slope=1.0, res_pre=None, res_post=None, out_dtype=None,
+              src_ab=0, flip=0):
+    """3x3x3 stride-1 convolution with `lp` (torch.bfloat16 / torch.float16) operands and fp32 accumulation; the folded
+    BatchNorm affine, activation and residual adds run in fp32 in the epilogue.  x may be fp32 (rounded on the fly) or
+    `lp`; the result (and the residuals) are `out_dtype` = `lp` (default) or fp32.  Forward only."""
+    code = LP_DTYPES[lp]
+    out_dtype = lp if out_dtype is None else out_dtype
+    x = _req_lp(x, "conv3d_lp", lp)
+    weight = _req(weight, "conv3d_lp.weight")
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
+        raise RuntimeError("conv3d_lp: the reduced-precision path is inference only (wrap the call in torch.no_grad())")
+    N, Cin, D, H, W = x.shape
+    Cout = weight.shape[1] if src_ab else weight.shape[0]
+    assert (weight.shape[0] if src_ab else weight.shape[1]) == Cin and tuple(weight.shape[2:]) == (3, 3, 3)
+    lib = _L()
+    for r in (res_pre, res_post):
+        if r is not None and (r.dtype != out_dtype or tuple(r.shape) != (N, Cout, D, H, W)):
+            raise RuntimeError("conv3d_lp: residuals must have the output's shape and dtype")
+    res_pre = None if res_pre is None else _req_lp(res_pre, "conv3d_lp.res_pre", lp)
+    res_post = None if res_post is None else _req_lp(res_post, "conv3d_lp.res_post", lp)
+    with torch.cuda.device_of(x):
+        def build():
+            wx = torch.empty((lib.dca_conv3d_lp_weight_bytes(Cin, Cout) // 2,), device=x.device, dtype=torch.int16)
+            _chk(lib.dca_conv3d_lp_prep_weight(_ptr(weight), _ptr(wx), Cin, Cout, int(src_ab), int(flip), code, _stream()),
+                 "dca_conv3d_lp_prep_weight")
+            return wx
+        wx = _memo(("lpprep", Cin, Cout, int(src_ab), int(flip), code), (weight,), build)
+        y = torch.empty((N, Cout, D, H, W), device=x.device, dtype=out_dtype)
+        _chk(lib.dca_conv3d_lp_forward(_ptr(x), _ptr(wx), _ptr(y), _ptr(_opt(scale, "scale")), _ptr(_opt(shift, "shift")),
+                                       _ptr(res_pre), _ptr(res_post), float(slope), N, Cin, Cout, D, H, W, code,
+                                       int(x.dtype == torch.float32), int(out_dtype == torch.float32), _stream()),
+             "dca_conv3d_lp_forward")
+    return y

@@ -207,6 +207,22 @@ int dca_focal_loss_bwd(const float* const* ests, float* const* gests, const floa
                        const double* work, const float* gloss, int B, int K, long HW, float focal_coefficient,
                        hipStream_t stream);
 
+/* ---- reduced-precision inference path (BASELINE configs 2 "bf16" and 5 "fp16") ---------------------------------
+ * Activations stored as bf16 / fp16, ONE native MFMA product per multiply, fp32 accumulation and fp32 epilogue
+ * arithmetic (folded BatchNorm affine, activation, residuals); forward only.  dtype codes: */
+#define DCA_BF16 1
+#define DCA_FP16 2
+/* 3x3x3 stride-1 convolution (convbn_3d + ReLU of models/submodule.py:121-124 in eval mode).  wx: dca_conv3d_lp_weight_bytes
+ * bytes, filled by dca_conv3d_lp_prep_weight (A, B, src_ab, flip as in dca_conv3d_prep_weight).  x: (N,Cin,D,H,W) in the
+ * 2-byte type, or fp32 when in_f32; y, res_pre, res_post: (N,Cout,D,H,W) in the 2-byte type, or fp32 when out_f32.
+ * y = act(conv * scale + shift + res_pre) + res_post. */
+long dca_conv3d_lp_weight_bytes(int Cin, int Cout);
+int dca_conv3d_lp_prep_weight(const float* w, void* wx, int A, int B, int src_ab, int flip, int dtype,
+                              hipStream_t stream);
+int dca_conv3d_lp_forward(const void* x, const void* wx, void* y, const float* scale, const float* shift,
+                          const void* res_pre, const void* res_post, float slope, int N, int Cin, int Cout, int D, int H,
+                          int W, int dtype, int in_f32, int out_f32, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

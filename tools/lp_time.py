@@ -1,0 +1,37 @@
+"""Micro-benchmark of the reduced-precision 3x3x3 conv (conv3d_lp.hip) at the BASELINE volume size, next to the
+fp32-grade bf16x3 kernel."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import dcanet_amd
+from dcanet_amd import ops
+
+d, h, w = 48, 136, 240
+dev = "cuda"
+wgt = torch.randn(32, 32, 3, 3, 3, device=dev) * 0.05
+sc, sh = torch.rand(32, device=dev) + 0.5, torch.randn(32, device=dev) * 0.1
+
+
+def timeit(fn, reps=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+with torch.no_grad(), ops.frozen_weights():
+    x32 = torch.randn(1, 32, d, h, w, device=dev)
+    ms = timeit(lambda: ops.conv3d_fused_inference(x32, wgt, 1, False, sc, sh, 0.0))
+    print(f"bf16x3 fp32->fp32            {ms*1e3:8.1f} us   {401.2/ms/1e3:6.2f} TB/s algorithmic")
+    for lp in (torch.bfloat16, torch.float16):
+        xl = x32.to(lp)
+        for xin, odt, name, mb in ((x32, torch.float32, "f32->f32", 401.2), (x32, lp, "f32->lp ", 300.9),
+                                   (xl, lp, "lp ->lp ", 200.6)):
+            ms = timeit(lambda: ops.conv3d_lp(xin, wgt, lp, sc, sh, 0.0, None, None, odt))
+            print(f"lp {str(lp)[6:]:9s} {name}        {ms*1e3:8.1f} us   {mb/ms/1e3:6.2f} TB/s algorithmic")
