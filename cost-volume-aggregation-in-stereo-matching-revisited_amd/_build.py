@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libdca_hip.so")
 HEADER = os.path.join(HERE, "..", "include", "dca_hip.h")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + os.environ.get("DCA_EXTRA_CFLAGS", "").split()
 
 
 def sources():

@@ -666,6 +666,8 @@ def bn_act(y, bn, slope=1.0, res_pre=None, res_post=None):
     """Applies the nn.BatchNorm3d module `bn` (parameters/buffers only; its forward is never called)."""
     momentum = 0.1 if bn.momentum is None else bn.momentum
     training = bn.training or bn.running_mean is None
+    if _lp_dtype() is not None:
+        raise RuntimeError("ops.reduced_precision is inference only: call the model in eval mode under torch.no_grad()")
     z = _BnAct.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, float(slope),
                      res_pre, res_post)
     if bn.training and bn.num_batches_tracked is not None:
@@ -677,6 +679,32 @@ def bn_act(y, bn, slope=1.0, res_pre=None, res_post=None):
     return z
 
 
+class reduced_precision:
+    """Inference-only context (BASELINE configs 2 "bf16" / 5 "fp16"): inside it the fused conv + BatchNorm inference
+    launches of the 3x3x3 stride-1 convolutions use `dtype` (torch.bfloat16 / torch.float16) operands with ONE native
+    MFMA product per multiply and fp32 accumulation (csrc/conv3d_lp.hip) instead of the fp32-grade six-product split.
+    Softmax, soft-argmin, BatchNorm folding, the context injection's arg-max / region softmax and the 32 -> 1 logit
+    heads stay fp32.  Per thread; never active outside the context; training (autograd) raises."""
+
+    def __init__(self, dtype):
+        if dtype not in LP_DTYPES:
+            raise ValueError("reduced_precision: torch.bfloat16 or torch.float16")
+        self.dtype = dtype
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "lp", None)
+        _tls.lp = self.dtype
+        return self
+
+    def __exit__(self, *exc):
+        _tls.lp = self.prev
+        return False
+
+
+def _lp_dtype():
+    return getattr(_tls, "lp", None)
+
+
 def convbn3d(x, conv, bn, slope=1.0, res_pre=None, res_post=None, x2=None):
     """`convbn_3d` (models/submodule.py:121-124) + activation + residual adds, on the HIP kernels.
 
@@ -686,6 +714,13 @@ def convbn3d(x, conv, bn, slope=1.0, res_pre=None, res_post=None, x2=None):
     transposed = isinstance(conv, torch.nn.ConvTranspose3d)
     stride = conv.stride[0]
     if not bn.training and not torch.is_grad_enabled():
+        lp = _lp_dtype()
+        if lp is not None and not transposed and stride == 1 and conv.kernel_size[0] == 3 and x2 is None:
+            with torch.cuda.device_of(x):
+                stats = bn_eval_affine(bn)
+            C = bn.num_features
+            return conv3d_lp(x, conv.weight, lp, stats[2 * C:3 * C], stats[3 * C:], slope, res_pre, res_post,
+                             out_dtype=x.dtype)
         xx = _req(x, "convbn3d")
         with torch.cuda.device_of(xx):
             stats = bn_eval_affine(bn)

@@ -25,6 +25,9 @@ CASES = [  # N, Cin, Cout, (D,H,W), in_f32, out_f32, affine, slope, pre, post
     (1, 32, 32, (6, 10, 18), False, True, False, 1.0, False, False),   # W % 4 != 0 (unaligned staging), fp32 out
     (1, 16, 27, (6, 6, 12), True, True, True, 0.1, True, True),        # partial channel chunk / block, both residuals
     (1, 32, 32, (9, 17, 33), False, False, True, 0.0, True, False),    # odd sizes, partial tiles everywhere
+    (1, 128, 64, (4, 8, 20), False, False, True, 0.0, False, False),   # 8 chunks: streaming-weights mode
+    (1, 80, 32, (5, 9, 17), True, False, False, 1.0, False, True),     # streaming mode, unaligned
+    (2, 32, 32, (8, 16, 32), False, False, True, 0.0, True, True),     # several tiles per workgroup range, both residuals
 ]
 
 
@@ -64,3 +67,64 @@ def test_conv3d_lp_refuses_training():
     w = torch.zeros(32, 32, 3, 3, 3, device=DEV, requires_grad=True)
     with pytest.raises(RuntimeError, match="inference only"):
         ops.conv3d_lp(x, w, torch.bfloat16)
+
+
+def _seeded_model(maxdisp):
+    from oracle import dcanet_oracle as O
+    from dcanet_amd.models.gwcnet_dca_g import GwcNet
+    m = GwcNet(maxdisp, use_concat_volume=False)
+    sd = O.seeded_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()})
+    m.load_state_dict(sd, strict=True)
+    return m.to(DEV).eval(), sd
+
+
+@pytest.mark.timeout(1200)
+def test_reduced_precision_epe_gate_full_size(capsys):
+    """SURVEY 8(d) gate for BASELINE configs 2 (bf16) and 5 (fp16) at 544x960 / D=192, eval forward from the 1/4-res
+    features through the convex up-sampler: |EPE_build - EPE_ref| <= 1e-3 against a common dense synthetic ground truth
+    (U(1,191), the bench's own), where ref = the fp32 CPU oracle on identical inputs and weights.  The mean / max
+    per-pixel deviation from the fp32 oracle is reported (expected floor with 8-bit-mantissa operands through ~40 layers:
+    ~1e-1 px bf16, ~1e-2 px fp16 -- SURVEY Appendix E.3), and bounded loosely so a broken kernel cannot hide in the EPE."""
+    from oracle import dcanet_oracle as O
+    from dcanet_amd import ops
+    m, sd = _seeded_model(192)
+    fL, fR = seeded_tensor("full.fL", (1, 320, 136, 240)), seeded_tensor("full.fR", (1, 320, 136, 240))
+    guid = seeded_tensor("full.guid", (1, 64, 136, 240))
+    gt = torch.rand(1, 1, 544, 960, generator=torch.Generator().manual_seed(5)) * 190.0 + 1.0
+    with torch.no_grad():
+        ref_q = O.hot_path(sd, fL, fR, 192, False)["pred4_q"]
+        ref = O.prop(sd, guid, ref_q, False)
+        f32 = m.prop(guid.to(DEV), m.hot_path(fL.to(DEV), fR.to(DEV))["pred4_q"]).cpu()
+    near = ref + torch.randn(ref.shape, generator=torch.Generator().manual_seed(6))      # a ground truth close to the prediction
+    epe = lambda x, g: (x - g).abs().mean().item()
+    rows = [("fp32 kernels", f32)]
+    for lp in LPS:
+        with torch.no_grad(), ops.reduced_precision(lp):
+            full = m.prop(guid.to(DEV), m.hot_path(fL.to(DEV), fR.to(DEV))["pred4_q"]).cpu()
+        rows.append((str(lp)[6:], full))
+    with capsys.disabled():
+        print(f"\n[reduced precision, 544x960 D=192] EPE_ref(U(1,191) GT) = {epe(ref, gt):.4f}, EPE_ref(near GT) = {epe(ref, near):.4f}")
+        for name, full in rows:
+            dev = (full - ref).abs()
+            print(f"   {name:12s} |dEPE| uniform GT {abs(epe(full, gt) - epe(ref, gt)):.2e}   near GT {abs(epe(full, near) - epe(ref, near)):.2e}"
+                  f"   mean|d| {dev.mean().item():.3e}   max|d| {dev.max().item():.3e}")
+    assert (f32 - ref).abs().max().item() <= 1e-3
+    for name, full in rows[1:]:
+        assert abs(epe(full, gt) - epe(ref, gt)) <= 1e-3, name
+        dev = (full - ref).abs()
+        assert dev.mean().item() <= (0.3 if name == "bfloat16" else 0.05), (name, dev.mean().item())
+
+
+def test_reduced_precision_is_inference_only():
+    from dcanet_amd import ops
+    m, _ = _seeded_model(32)
+    fL = seeded_tensor("lp.tr.fL", (1, 320, 16, 32)).to(DEV)
+    with ops.reduced_precision(torch.bfloat16):
+        with pytest.raises(RuntimeError, match="inference only"):
+            m.train().hot_path(fL, fL)
+    with torch.no_grad():      # and the context leaves nothing behind
+        a = m.eval().hot_path(fL, fL)["pred4_q"]
+        with ops.reduced_precision(torch.float16):
+            b = m.hot_path(fL, fL)["pred4_q"]
+        c = m.hot_path(fL, fL)["pred4_q"]
+    assert torch.equal(a, c) and not torch.equal(a, b)
