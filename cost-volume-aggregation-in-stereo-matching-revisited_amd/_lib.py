@@ -50,6 +50,9 @@ SIGNATURES = {
     "dca_conv3d_lp_weight_bytes": (_l, [_i, _i]),
     "dca_conv3d_lp_prep_weight": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "dca_conv3d_lp_forward": (_i, [_p] * 7 + [_f] + [_i] * 9 + [_p]),
+    "dca_conv1_lp_weight_bytes": (_l, [_i, _i]),
+    "dca_conv1_lp_prep_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "dca_conv1_lp_forward": (_i, [_p] * 8 + [_f, _i, _i, _i, _i, _l, _i, _i, _p]),
     "dca_convex_up4_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "dca_convex_up4_bwd": (_i, [_p] * 6 + [_i, _i, _i, _p]),
     "dca_focal_loss_workspace": (_l, [_i, _i, _l]),

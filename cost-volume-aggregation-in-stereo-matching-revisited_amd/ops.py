@@ -994,3 +994,41 @@ def conv3d_lp(x, weight, lp, scale=None, shift=None, slope=1.0, res_pre=None, re
                                        int(x.dtype == torch.float32), int(out_dtype == torch.float32), _stream()),
              "dca_conv3d_lp_forward")
     return y
+
+
+def conv1x1_lp(x, weight, lp, x2=None, scale=None, shift=None, slope=1.0, res_pre=None, res_post=None, out_dtype=None):
+    """1x1x1 convolution (Cout <= 32) over one or two `lp` inputs (implicit channel concat), fp32 accumulation, fused
+    affine + activation + residual epilogue; result `lp` (default) or fp32.  weight: (Cout, C1 + C2[,1,1,1]) fp32."""
+    code = LP_DTYPES[lp]
+    out_dtype = lp if out_dtype is None else out_dtype
+    x = _req_lp(x, "conv1x1_lp", lp)
+    x2 = None if x2 is None else _req_lp(x2, "conv1x1_lp.x2", lp)
+    if x.dtype != lp or (x2 is not None and x2.dtype != lp):
+        raise RuntimeError(f"conv1x1_lp: inputs must be {lp}")
+    weight = _req(weight, "conv1x1_lp.weight")
+    N, C1 = x.shape[0], x.shape[1]
+    C2 = 0 if x2 is None else x2.shape[1]
+    Cout = weight.shape[0]
+    S = x[0, 0].numel()
+    assert weight[0].numel() == C1 + C2, "conv1x1_lp: channel mismatch"
+    if Cout > 32 or S % 4:
+        raise RuntimeError("conv1x1_lp: at most 32 output channels and a voxel count divisible by 4")
+    lib = _L()
+    oshape = (N, Cout) + tuple(x.shape[2:])
+    for r in (res_pre, res_post):
+        if r is not None and (r.dtype != out_dtype or tuple(r.shape) != oshape):
+            raise RuntimeError("conv1x1_lp: residuals must have the output's shape and dtype")
+    res_pre = None if res_pre is None else _req_lp(res_pre, "conv1x1_lp.res_pre", lp)
+    res_post = None if res_post is None else _req_lp(res_post, "conv1x1_lp.res_post", lp)
+    with torch.cuda.device_of(x):
+        def build():
+            wf = torch.empty((lib.dca_conv1_lp_weight_bytes(C1, C2) // 2,), device=x.device, dtype=torch.int16)
+            _chk(lib.dca_conv1_lp_prep_weight(_ptr(weight), _ptr(wf), Cout, C1, C2, code, _stream()),
+                 "dca_conv1_lp_prep_weight")
+            return wf
+        wf = _memo(("lp1prep", Cout, C1, C2, code), (weight,), build)
+        y = torch.empty(oshape, device=x.device, dtype=out_dtype)
+        _chk(lib.dca_conv1_lp_forward(_ptr(x), _ptr(x2), _ptr(wf), _ptr(y), _ptr(_opt(scale, "scale")),
+                                      _ptr(_opt(shift, "shift")), _ptr(res_pre), _ptr(res_post), float(slope), N, C1, C2,
+                                      Cout, S, code, int(out_dtype == torch.float32), _stream()), "dca_conv1_lp_forward")
+    return y

@@ -223,6 +223,16 @@ int dca_conv3d_lp_forward(const void* x, const void* wx, void* y, const float* s
                           const void* res_pre, const void* res_post, float slope, int N, int Cin, int Cout, int D, int H,
                           int W, int dtype, int in_f32, int out_f32, hipStream_t stream);
 
+/* 1x1x1 convolution (pointwise GEMM), Cout <= 32, over one or two 2-byte inputs (implicit channel concat: the `fuse` conv
+ * of models/augment/cva.py:55,69; `cost_agg.redir`, cva.py:23; the tap-expansion GEMM of the logit heads).  w: (Cout,
+ * C1 + C2) fp32 row major -> wfrag (dca_conv1_lp_weight_bytes bytes).  x: (N,C1,S), x2: (N,C2,S) or NULL (C2 = 0);
+ * y / res_pre / res_post: (N,Cout,S) in the 2-byte type, or fp32 when out_f32.  S % 4 == 0. */
+long dca_conv1_lp_weight_bytes(int C1, int C2);
+int dca_conv1_lp_prep_weight(const float* w, void* wfrag, int Cout, int C1, int C2, int dtype, hipStream_t stream);
+int dca_conv1_lp_forward(const void* x, const void* x2, const void* wfrag, void* y, const float* scale,
+                         const float* shift, const void* res_pre, const void* res_post, float slope, int N, int C1,
+                         int C2, int Cout, long S, int dtype, int out_f32, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,46 @@ def test_conv3d_lp(case, lp):
     assert (err <= lim).all(), f"max err {err.max().item():.3e} at |ref| {ref.abs().flatten()[err.argmax()].item():.3e}"
 
 
+C1_CASES = [  # N, C1, C2, Cout, dims, out_f32, affine, slope, pre, post
+    (1, 32, 0, 32, (4, 8, 16), False, True, 0.1, False, False),
+    (2, 32, 32, 32, (3, 5, 12), False, True, 1.0, False, False),      # fuse: two inputs
+    (1, 32, 0, 27, (6, 7, 20), True, False, 1.0, False, False),       # tap expansion of a logit head: 27 fp32 outputs
+    (1, 32, 0, 32, (5, 9, 28), False, True, 0.0, True, True),         # redir-style with both residuals, ragged last group
+    (1, 40, 24, 20, (2, 3, 8), True, True, 0.1, True, False),         # partial chunks in both inputs
+]
+
+
+@pytest.mark.parametrize("lp", LPS, ids=["bf16", "fp16"])
+@pytest.mark.parametrize("case", C1_CASES, ids=[str(c[:5]) for c in C1_CASES])
+def test_conv1x1_lp(case, lp):
+    from dcanet_amd import ops
+    N, C1, C2, Cout, dims, out32, aff, slope, pre, post = case
+    x = seeded_tensor(f"lp1.x{case}", (N, C1) + dims).to(lp)
+    x2 = seeded_tensor(f"lp1.y{case}", (N, C2) + dims).to(lp) if C2 else None
+    w = seeded_tensor(f"lp1.w{case}", (Cout, C1 + C2, 1, 1, 1)) * (2.0 / (C1 + C2)) ** 0.5
+    odt = torch.float32 if out32 else lp
+    scale = (torch.rand(Cout) + 0.5) if aff else None
+    shift = torch.randn(Cout) * 0.1 if aff else None
+    rp = seeded_tensor(f"lp1.p{case}", (N, Cout) + dims).to(odt) if pre else None
+    rq = seeded_tensor(f"lp1.q{case}", (N, Cout) + dims).to(odt) if post else None
+    xin = x if x2 is None else torch.cat([x, x2], 1)
+    ref = F.conv3d(xin.double(), w.to(lp).double())
+    if aff:
+        ref = ref * scale.double().view(1, -1, 1, 1, 1) + shift.double().view(1, -1, 1, 1, 1)
+    if pre:
+        ref = ref + rp.double()
+    ref = torch.where(ref > 0, ref, ref * slope)
+    if post:
+        ref = ref + rq.double()
+    g = lambda t: None if t is None else t.to(DEV)
+    with torch.no_grad():
+        got = ops.conv1x1_lp(g(x), g(w), lp, g(x2), g(scale), g(shift), slope, g(rp), g(rq), odt)
+    assert got.dtype == odt and got.shape == ref.shape
+    err = (got.double().cpu() - ref).abs()
+    lim = 2e-5 * max(1.0, ref.abs().max().item()) + (0 if out32 else ulp(lp)) * ref.abs()
+    assert (err <= lim).all(), f"max err {err.max().item():.3e}"
+
+
 def test_conv3d_lp_refuses_training():
     from dcanet_amd import ops
     x = torch.zeros(1, 32, 4, 8, 16, device=DEV, dtype=torch.bfloat16)

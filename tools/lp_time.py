@@ -36,3 +36,17 @@ with torch.no_grad(), ops.frozen_weights():
                                    (xl, lp, "lp ->lp ", 200.6)):
             ms = timeit(lambda: ops.conv3d_lp(xin, wgt, lp, sc, sh, 0.0, None, None, odt))
             print(f"lp {str(lp)[6:]:9s} {name}        {ms*1e3:8.1f} us   {mb/ms/1e3:6.2f} TB/s algorithmic")
+
+with torch.no_grad(), ops.frozen_weights():
+    w1 = torch.randn(32, 32, 1, 1, 1, device=dev) * 0.1
+    w2 = torch.randn(32, 64, 1, 1, 1, device=dev) * 0.1
+    for lp in (torch.bfloat16, torch.float16):
+        xl = x32.to(lp)
+        ms = timeit(lambda: ops.conv1x1_lp(xl, w1, lp, None, sc, sh, 0.1))
+        print(f"conv1 lp {str(lp)[6:]:9s} 32->32       {ms*1e3:8.1f} us   {200.6/ms/1e3:6.2f} TB/s algorithmic")
+        ms = timeit(lambda: ops.conv1x1_lp(xl, w2, lp, xl, sc, sh, 1.0))
+        print(f"conv1 lp {str(lp)[6:]:9s} 64->32 (2 in) {ms*1e3:8.1f} us   {300.9/ms/1e3:6.2f} TB/s algorithmic")
+    ms = timeit(lambda: ops.conv3d_fused_inference(x32, w1, 1, False, sc, sh, 0.1))
+    print(f"conv1 fp32 32->32                {ms*1e3:8.1f} us   {401.2/ms/1e3:6.2f} TB/s algorithmic")
+    ms = timeit(lambda: ops.conv3d_fused_inference(x32, w2, 1, False, sc, sh, 1.0, x2=x32))
+    print(f"conv1 fp32 64->32 (2 in)         {ms*1e3:8.1f} us   {601.8/ms/1e3:6.2f} TB/s algorithmic")
