@@ -277,6 +277,10 @@ def main():
                     help="stereo pairs per GPU (weak scaling); default 4 for the training step -- BASELINE.json configs[2] "
                          "(fwd+bwd, batch=4) and configs[3] (8 GPUs, batch=32) -- and 1 for the eval forward (configs[1])")
     ap.add_argument("--mode", choices=["fwdbwd", "fwd"], default="fwdbwd")
+    ap.add_argument("--dtype", choices=["f32", "bf16", "fp16"], default="f32",
+                    help="f32 (default, the headline: fp32 storage, fp32-grade arithmetic) or the reduced-precision INFERENCE "
+                         "path of BASELINE configs 2 / 5 (2-byte storage of the 1/4-res tensors, one MFMA product per "
+                         "multiply, fp32 accumulation; --mode fwd only, EPE-gated in tests/test_gpu_lowprec.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=16)
     ap.add_argument("--no-prepack", action="store_true", help="fwdbwd mode: re-lay-out each weight in its own launch")
@@ -290,6 +294,8 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))
 
+    if args.dtype != "f32" and args.mode != "fwd":
+        raise SystemExit("bench.py: --dtype bf16/fp16 is the reduced-precision INFERENCE path: use --mode fwd")
     if args.batch is None:
         args.batch = 4 if args.mode == "fwdbwd" else 1
     global H_IMG, W_IMG, MAXDISP
@@ -364,6 +370,8 @@ def main():
         # once (during warm-up) instead of per call -- ordinary inference-engine weight pre-packing
         from dcanet_amd import ops as _ops
         frozen.enter_context(_ops.frozen_weights())
+        if args.dtype != "f32":
+            frozen.enter_context(_ops.reduced_precision(torch.bfloat16 if args.dtype == "bf16" else torch.float16))
     for _ in range(args.warmup):
         step()
 
@@ -394,12 +402,17 @@ def main():
             "value": round(volumes / dt, 4), "unit": "cost-volumes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "dtype_note": ("fp32 tensors and fp32 accumulation everywhere; the 3x3x3 stride-1 convolutions and their weight "
                            "gradients evaluate each fp32 product exactly-split into three bf16 terms (six bf16 MFMA products, "
                            "dropped terms <= 2^-23): measured against fp64 as accurate as the fp32 MFMA kernels "
                            "(tests/test_gpu_parity.py::test_conv3d_bf16x3_is_fp32_grade); DCA_CONV=fp32 selects the fp32 MFMA "
-                           "kernels") if _conv_x3() else "fp32 MFMA kernels everywhere (DCA_CONV=fp32)",
+                           "kernels") if args.dtype == "f32" and _conv_x3() else
+                          ("fp32 MFMA kernels everywhere (DCA_CONV=fp32)" if args.dtype == "f32" else
+                           "reduced-precision inference path (NOT the headline): 1/4-res activations stored as " + args.dtype +
+                           ", one native MFMA product per multiply with fp32 accumulation in the 3x3x3 stride-1 and 1x1x1 "
+                           "convolutions, fp32 BN folding / softmax / soft-argmin / context injection / attention; gate "
+                           "|EPE - EPE_fp32 oracle| <= 1e-3 (tests/test_gpu_lowprec.py)"),
             "data": "synthetic",
             "config": {"workload": "gwcnet_dca_g (GwcNet-G + 3 DCA blocks) hot path from 1/4-res features, "
                                    f"{H_IMG}x{W_IMG} D={MAXDISP}, " + ("train step: fwd(all heads)+focal/model loss+bwd+allreduce+Adam"

@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(HERE, "libdca_hip.so")
 
 _p, _i, _l, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double
 
-ABI_VERSION = 2   # == DCA_ABI_VERSION of include/dca_hip.h
+ABI_VERSION = 3   # == DCA_ABI_VERSION of include/dca_hip.h
 
 # name -> (restype, argtypes); mirrors include/dca_hip.h one to one
 SIGNATURES = {
@@ -17,6 +17,7 @@ SIGNATURES = {
     "dca_gwc_volume_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "dca_concat_volume_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "dca_concat_volume_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "dca_cost_volume_fwd": (_i, [_p, _p, _p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     "dca_softargmin_fwd": (_i, [_p, _p, _i, _i, _l, _i, _p]),
     "dca_softargmin_bwd": (_i, [_p, _p, _p, _i, _i, _l, _i, _p]),
     "dca_up_softargmin_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
@@ -53,6 +54,9 @@ SIGNATURES = {
     "dca_conv1_lp_weight_bytes": (_l, [_i, _i]),
     "dca_conv1_lp_prep_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "dca_conv1_lp_forward": (_i, [_p] * 8 + [_f, _i, _i, _i, _i, _l, _i, _i, _p]),
+    "dca_conv3d_forward_mixed": (_i, [_p] * 7 + [_f] + [_i] * 12 + [_p]),
+    "dca_avgpool3d_lp_fwd": (_i, [_p, _p, _l, _i, _i, _i, _i, _p]),
+    "dca_trilinear_up2_lp_fwd": (_i, [_p, _p, _l, _i, _i, _i, _i, _p]),
     "dca_convex_up4_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "dca_convex_up4_bwd": (_i, [_p] * 6 + [_i, _i, _i, _p]),
     "dca_focal_loss_workspace": (_l, [_i, _i, _l]),

@@ -40,6 +40,25 @@ __device__ __forceinline__ float epilogue(const ConvArgs& a, float v, int co, lo
   return v;
 }
 
+// 2-byte storage types of the reduced-precision inference path (include/dca_hip.h: DCA_BF16 = 1, DCA_FP16 = 2); 0 = fp32.
+// The stride-2 convolution can READ them (XT) and the transposed convolution can WRITE them (YT, residuals included);
+// the arithmetic stays the exact-fp32 MFMA of this file.
+template <int DT> struct Two;
+template <> struct Two<1> { typedef __bf16 T; };
+template <> struct Two<2> { typedef _Float16 T; };
+template <int DT> __device__ __forceinline__ float two_lo(unsigned w) {
+  return (float)__builtin_bit_cast(typename Two<DT>::T, (unsigned short)(w & 0xffffu));
+}
+template <int DT> __device__ __forceinline__ float two_hi(unsigned w) {
+  return (float)__builtin_bit_cast(typename Two<DT>::T, (unsigned short)(w >> 16));
+}
+template <int DT> __device__ __forceinline__ unsigned two_pack(float a, float b) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef typename Two<DT>::T mtx2 __attribute__((ext_vector_type(2)));
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, mtx2));
+}
+
 // ---------------------------------------------------------------------------------------------
 // 3x3x3, pad 1, stride S.  Block = 4 waves; output tile TD x TH x TW; an MFMA column tile is 32 voxels =
 // (32/TW) consecutive H rows x TW consecutive W positions (TW = 32: one row; TW = 16: two rows, which lets
@@ -48,9 +67,11 @@ __device__ __forceinline__ float epilogue(const ConvArgs& a, float v, int co, lo
 // Aligned inputs (VEC) run a software pipeline: the next channel chunk's global loads (input halo tile and
 // weights) are issued into registers before the MFMA loop of the current chunk and written to LDS after it.
 // ---------------------------------------------------------------------------------------------
-template <int S, int CT, int CK, int TD, int TH, int TW, bool VEC>
+template <int S, int CT, int CK, int TD, int TH, int TW, bool VEC, int XT = 0>
 __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
   static_assert(TW == 32 || (TW == 16 && S == 1), "tile width");
+  static_assert(XT == 0 || VEC, "2-byte inputs take the aligned path");
+  constexpr int XSZ = XT == 0 ? 4 : 2;
   constexpr int RPT = 32 / TW;                 // H rows per MFMA tile
   constexpr int NT = TD * TH / RPT / 4;        // MFMA tiles per wave
   static_assert(NT * 4 * RPT == TD * TH, "tile shape");
@@ -97,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
 
   // Prefetch loads are hardware-predicated buffer loads (dca_common.h): straight-line code, masked elements -> 0.
   const long sample = (long)a.Cin * a.Di * a.Hi * a.Wi;
-  const __amdgpu_buffer_rsrc_t xr = dca_rsrc(a.x + (long)n * sample, sample * 4);
+  const __amdgpu_buffer_rsrc_t xr = dca_rsrc((const char*)a.x + (long)n * sample * XSZ, sample * XSZ);
   const __amdgpu_buffer_rsrc_t wr = dca_rsrc(a.wt, (long)27 * a.CinPad * CO * 4);
   const int cstride = a.Di * a.Hi * a.Wi;
   auto load_regs = [&](int ci0) __attribute__((always_inline)) {
@@ -109,7 +130,12 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
       const int ci = ci0 + c, di = di0 + id, hi = hi0 + ih, wi = wi0 + 1 + 4 * q;
       const int ok = (int)(it < ROWS * QPR) & (int)(ci < a.Cin) & (int)((unsigned)di < (unsigned)a.Di) &
                      (int)((unsigned)hi < (unsigned)a.Hi) & (int)(wi < a.Wi);
-      rx[k] = dca_bload4(xr, (ci * cstride + (di * a.Hi + hi) * a.Wi + wi) * 4, ok);
+      if constexpr (XT == 0) {
+        rx[k] = dca_bload4(xr, (ci * cstride + (di * a.Hi + hi) * a.Wi + wi) * 4, ok);
+      } else {   // four 2-byte values, kept raw until store_regs (a conversion here would wait for the load)
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(xr, dca_pred_off((ci * cstride + (di * a.Hi + hi) * a.Wi + wi) * 2, ok), 0, 0);
+        rx[k].x = __uint_as_float(v.x); rx[k].y = __uint_as_float(v.y);
+      }
     }
 #pragma unroll
     for (int k = 0; k < KH; ++k) {
@@ -119,7 +145,9 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
       const int ci = ci0 + c, di = di0 + id, hi = hi0 + ih, wi = wi0 + j;
       const int ok = (int)(it < ROWS * NH) & (int)(ci < a.Cin) & (int)((unsigned)di < (unsigned)a.Di) &
                      (int)((unsigned)hi < (unsigned)a.Hi) & (int)((unsigned)wi < (unsigned)a.Wi);
-      rh[k] = dca_bload1(xr, (ci * cstride + (di * a.Hi + hi) * a.Wi + wi) * 4, ok);
+      if constexpr (XT == 0) rh[k] = dca_bload1(xr, (ci * cstride + (di * a.Hi + hi) * a.Wi + wi) * 4, ok);
+      else rh[k] = __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(
+               xr, dca_pred_off((ci * cstride + (di * a.Hi + hi) * a.Wi + wi) * 2, ok), 0, 0));
     }
 #pragma unroll
     for (int k = 0; k < KW; ++k) {
@@ -132,11 +160,16 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
 #pragma unroll
     for (int k = 0; k < KX; ++k) {
       const int it = tid + 256 * k;
+      if constexpr (XT != 0) {
+        const unsigned w0_ = __float_as_uint(rx[k].x), w1_ = __float_as_uint(rx[k].y);
+        rx[k] = make_float4(two_lo<XT ? XT : 1>(w0_), two_hi<XT ? XT : 1>(w0_), two_lo<XT ? XT : 1>(w1_), two_hi<XT ? XT : 1>(w1_));
+      }
       if (it < ROWS * QPR) *(float4*)(in_lds + (it / QPR) * IWP + 4 + 4 * (it % QPR)) = rx[k];
     }
 #pragma unroll
     for (int k = 0; k < KH; ++k) {
       const int it = tid + 256 * k;
+      if constexpr (XT != 0) rh[k] = two_lo<XT ? XT : 1>(__float_as_uint(rh[k]));
       if (it < ROWS * NH) in_lds[(it / NH) * IWP + 3 + ((it % NH) ? (IW - 1) : 0)] = rh[k];
     }
 #pragma unroll
@@ -255,7 +288,7 @@ static int launch_conv3(ConvArgs& a, bool vec, hipStream_t stream);
 // x[m+1] / x[m].  Each wave owns one row of 32 coarse positions and keeps the 8 output-parity
 // classes in 8 accumulators; the 27 taps are distributed over them at compile time.
 // ---------------------------------------------------------------------------------------------
-template <int CK, bool VEC>
+template <int CK, bool VEC, int YT = 0>
 __global__ __launch_bounds__(256, 2) void deconv3_mfma_kernel(ConvArgs a) {
   constexpr int ID = 3, IH = 3, IWP = 40, CO = 32;
   constexpr int ROWS = CK * ID * IH;
@@ -400,14 +433,24 @@ __global__ __launch_bounds__(256, 2) void deconv3_mfma_kernel(ConvArgs a) {
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
             const int r = rc + q;
-            rp[q] = *(const float2*)(a.res_pre + base + min((r & 3) + 8 * (r >> 2) + 4 * half, a.Cout - 1) * plane);
+            const long off = base + min((r & 3) + 8 * (r >> 2) + 4 * half, a.Cout - 1) * plane;
+            if constexpr (YT == 0) rp[q] = *(const float2*)(a.res_pre + off);
+            else {
+              const unsigned w_ = *(const unsigned*)((const unsigned short*)a.res_pre + off);
+              rp[q] = make_float2(two_lo<YT ? YT : 1>(w_), two_hi<YT ? YT : 1>(w_));
+            }
           }
         }
         if (has_post) {
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
             const int r = rc + q;
-            rq[q] = *(const float2*)(a.res_post + base + min((r & 3) + 8 * (r >> 2) + 4 * half, a.Cout - 1) * plane);
+            const long off = base + min((r & 3) + 8 * (r >> 2) + 4 * half, a.Cout - 1) * plane;
+            if constexpr (YT == 0) rq[q] = *(const float2*)(a.res_post + off);
+            else {
+              const unsigned w_ = *(const unsigned*)((const unsigned short*)a.res_post + off);
+              rq[q] = make_float2(two_lo<YT ? YT : 1>(w_), two_hi<YT ? YT : 1>(w_));
+            }
           }
         }
 #pragma unroll
@@ -417,7 +460,10 @@ __global__ __launch_bounds__(256, 2) void deconv3_mfma_kernel(ConvArgs a) {
           if (has_pre) { o.x += rp[q].x; o.y += rp[q].y; }
           o.x = act_apply(o.x, a.slope); o.y = act_apply(o.y, a.slope);
           if (has_post) { o.x += rq[q].x; o.y += rq[q].y; }
-          if (ok && co < a.Cout) *(float2*)(a.y + base + co * plane) = o;
+          if (ok && co < a.Cout) {
+            if constexpr (YT == 0) *(float2*)(a.y + base + co * plane) = o;
+            else *(unsigned*)((unsigned short*)a.y + base + co * plane) = two_pack<YT ? YT : 1>(o.x, o.y);
+          }
         }
       }
     }
@@ -654,4 +700,54 @@ extern "C" int dca_conv3d_forward(const float* x, const float* x2, const float* 
   // 1 x 4 x 32 tiles with 2-channel chunks (29 KB of LDS, 123 registers -> four workgroups per CU): 265 -> 243 us.
   if ((long)N * cdiv(Do, 2) * cdiv(Ho, 4) * cdiv(Wo, 32) < 2048) return launch_conv3<2, 2, 2, 1, 4, 32>(a, vec, stream);
   return launch_conv3<2, 2, 4, 2, 4, 32>(a, vec, stream);
+}
+
+
+// Mixed-storage launches of the reduced-precision inference path (the arithmetic is this file's exact-fp32 MFMA):
+//   transposed == 0: 3x3x3 stride-2 convolution reading a 2-byte x (dtype), writing fp32 y (cost_agg.conv1, cva.py:16-17)
+//   transposed == 1: ConvTranspose3d(3, s2, p1, op1) reading fp32 x, writing y and reading res_pre / res_post in the
+//                    2-byte type (cost_agg.conv3 + ReLU(. + redir) [+ outer residual], cva.py:21-29)
+extern "C" int dca_conv3d_forward_mixed(const void* x, const float* wt, void* y, const float* scale, const float* shift,
+                                        const void* res_pre, const void* res_post, float slope, int N, int Cin, int Cout,
+                                        int CinPad, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int transposed,
+                                        int dtype, hipStream_t stream) {
+  DCA_REQUIRE(x && wt && y && N > 0 && Cin > 0 && Cout > 0 && CinPad >= Cin && CinPad % 8 == 0);
+  DCA_REQUIRE(dtype == DCA_BF16 || dtype == DCA_FP16);
+  DCA_REQUIRE((scale == nullptr) == (shift == nullptr));
+  DCA_REQUIRE(Wi % 4 == 0 && (long)Cin * Di * Hi * Wi * 4 < 0x7ffffff0L);
+  DCA_REQUIRE(((((uintptr_t)x | (uintptr_t)y | (uintptr_t)wt | (uintptr_t)res_pre | (uintptr_t)res_post)) & 15) == 0);
+  ConvArgs a;
+  a.x = (const float*)x; a.x2 = nullptr; a.wt = wt; a.y = (float*)y; a.scale = scale; a.shift = shift;
+  a.res_pre = (const float*)res_pre; a.res_post = (const float*)res_post; a.slope = slope;
+  a.N = N; a.Cin = Cin; a.Cout = Cout; a.CinPad = CinPad; a.CoutTotal = Cout; a.co_off = 0;
+  a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Do = Do; a.Ho = Ho; a.Wo = Wo;
+  a.nTD = a.nTH = a.nTW = 1; a.xs_n = a.x2s_n = 0;
+  if (transposed) {
+    DCA_REQUIRE(Cout <= 32 && Do == 2 * Di && Ho == 2 * Hi && Wo == 2 * Wi);
+    a.nTD = cdiv(Di, 2); a.nTH = cdiv(Hi, 2); a.nTW = cdiv(Wi, 32);
+    const int grid = N * a.nTD * a.nTH * a.nTW;
+    const size_t lds = (size_t)(8 * 9 * 40 + 27 * 8 * 32) * 4;
+    return dtype == DCA_BF16 ? launch_conv(deconv3_mfma_kernel<8, true, 1>, a, grid, lds, stream)
+                             : launch_conv(deconv3_mfma_kernel<8, true, 2>, a, grid, lds, stream);
+  }
+  DCA_REQUIRE(res_pre == nullptr && res_post == nullptr);   // (fp32 residual reads are not wired for this form)
+  DCA_REQUIRE(Cout <= 64 && Do == (Di + 1) / 2 && Ho == (Hi + 1) / 2 && Wo == (Wi + 1) / 2);
+  constexpr int CT = 2;
+  const bool small = (long)N * cdiv(Do, 2) * cdiv(Ho, 4) * cdiv(Wo, 32) < 2048;
+  if (small) {
+    constexpr int CK = 2, TD = 1, TH = 4, TW = 32, S = 2;
+    constexpr int ID = (TD - 1) * S + 3, IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3, IWP = ((3 + IW + 3) / 4) * 4;
+    const size_t lds = (size_t)(CK * ID * IH * IWP + 27 * CK * CT * 32) * 4;
+    a.nTD = cdiv(Do, TD); a.nTH = cdiv(Ho, TH); a.nTW = cdiv(Wo, TW);
+    const int grid = N * a.nTD * a.nTH * a.nTW;
+    return dtype == DCA_BF16 ? launch_conv(conv3_mfma_kernel<S, CT, CK, TD, TH, TW, true, 1>, a, grid, lds, stream)
+                             : launch_conv(conv3_mfma_kernel<S, CT, CK, TD, TH, TW, true, 2>, a, grid, lds, stream);
+  }
+  constexpr int CK = 4, TD = 2, TH = 4, TW = 32, S = 2;
+  constexpr int ID = (TD - 1) * S + 3, IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3, IWP = ((3 + IW + 3) / 4) * 4;
+  const size_t lds = (size_t)(CK * ID * IH * IWP + 27 * CK * CT * 32) * 4;
+  a.nTD = cdiv(Do, TD); a.nTH = cdiv(Ho, TH); a.nTW = cdiv(Wo, TW);
+  const int grid = N * a.nTD * a.nTH * a.nTW;
+  return dtype == DCA_BF16 ? launch_conv(conv3_mfma_kernel<S, CT, CK, TD, TH, TW, true, 1>, a, grid, lds, stream)
+                           : launch_conv(conv3_mfma_kernel<S, CT, CK, TD, TH, TW, true, 2>, a, grid, lds, stream);
 }

@@ -15,10 +15,12 @@ class GraphedHotPath:
     the same shapes to replay.  Returns the dict of outputs (static buffers: clone them if they must outlive the
     next call)."""
 
-    def __init__(self, model, *example_inputs: torch.Tensor, warmup: int = 2):
+    def __init__(self, model, *example_inputs, warmup: int = 2):
+        """example_inputs: the arguments of `model.hot_path` -- tensors, or tuples of tensors (the extractor's l2 / l3 /
+        l4 segments), or None"""
         assert not model.training, "graph capture is for the eval path (training BN updates buffers)"
         self.model = model
-        self.static_in = [t.detach().clone() for t in example_inputs]
+        self.static_in = [_tree(t, lambda u: u.detach().clone()) for t in example_inputs]
         stream = torch.cuda.Stream()
         stream.wait_stream(torch.cuda.current_stream())
         with torch.no_grad(), torch.cuda.stream(stream):
@@ -29,12 +31,34 @@ class GraphedHotPath:
         with torch.no_grad(), torch.cuda.graph(self.graph):
             self.static_out = model.hot_path(*self.static_in)
 
-    def __call__(self, *inputs: torch.Tensor):
+    def __call__(self, *inputs):
         for s, t in zip(self.static_in, inputs):
-            assert s.shape == t.shape, "graph was captured for a different shape"
-            s.copy_(t)
+            _tree2(s, t, _copy_checked)
         self.graph.replay()
         return self.static_out
+
+
+def _tree(t, fn):
+    if t is None:
+        return None
+    if isinstance(t, (tuple, list)):
+        return tuple(_tree(u, fn) for u in t)
+    return fn(t)
+
+
+def _tree2(s, t, fn):
+    if s is None:
+        return
+    if isinstance(s, tuple):
+        for a, b in zip(s, t):
+            _tree2(a, b, fn)
+    else:
+        fn(s, t)
+
+
+def _copy_checked(s, t):
+    assert s.shape == t.shape, "graph was captured for a different shape"
+    s.copy_(t)
 
 
 class GraphedTrainStep:

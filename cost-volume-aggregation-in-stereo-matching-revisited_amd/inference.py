@@ -75,7 +75,7 @@ class KittiInference:
         net = self.net
         fl, fr = net.feature_extraction(left), net.feature_extraction(right)
         guidance = net.guidance(left)["g"]
-        args = [fl["gwc_feature"], fr["gwc_feature"]]
+        args = [fl["gwc_segments"], fr["gwc_segments"]]
         if net.use_concat_volume:
             args += [fl["concat_feature"], fr["concat_feature"]]
         if self.graph:

@@ -1,4 +1,5 @@
 """Mirror of the reference's models/augment/cva.py (Multi_Aggregation, cva) on HIP kernels."""
+import torch
 import torch.nn as nn
 
 from .._bootstrap import ensure as _ensure
@@ -55,7 +56,10 @@ class _Classify(nn.Sequential):
                          nn.Conv3d(c, 1, kernel_size=3, padding=1, stride=1, bias=False))
 
     def forward(self, x):
-        return conv3d_plain(self[0](x, slope=0.0), self[2])
+        h = self[0](x, slope=0.0)
+        if h.dtype != torch.float32:            # reduced-precision inference: 2-byte features, fp32 logits
+            return ops.conv3d_c1_lp(h, self[2].weight)
+        return conv3d_plain(h, self[2])
 
 
 class cva(nn.Module):
@@ -73,7 +77,32 @@ class cva(nn.Module):
         self.fuse = nn.Sequential(ConvBn3d(64, 32, 1, 1, 0))
         self.cost_agg = Multi_Aggregation(self.channel)
 
+    def _forward_lp(self, x, res_post):
+        """Reduced-precision inference (ops.reduced_precision): the 1/4-resolution tensors (x, aug, fuse / redir / deconv
+        outputs) are stored in the 2-byte type, the 1/8-resolution interior (pooled volume, logits, context injection,
+        attention) stays fp32 storage with single-product convolutions."""
+        lp = x.dtype
+        aff = lambda bn: (lambda st, C: (st[2 * C:3 * C], st[3 * C:]))(ops.bn_eval_affine(bn), bn.num_features)
+        cost_down = self.downsample[1](ops.avg_pool3d_lp(x), slope=0.0)
+        prob_volume = self.classify(cost_down).squeeze(1)
+        aug = ops.trilinear_up2_lp(self.slc_net(cost_down, prob_volume), lp)
+        sc, sh = aff(self.fuse[0][1])
+        fused = ops.conv1x1_lp(aug, self.fuse[0][0].weight, lp, x2=x, scale=sc, shift=sh, slope=1.0)
+        agg = self.cost_agg
+        sc, sh = aff(agg.conv1[0][1])
+        c1 = ops.conv3d_s2_lp(fused, agg.conv1[0][0].weight, sc, sh, 0.0)
+        c2 = agg.conv2(c1)
+        sc, sh = aff(agg.redir[1])
+        skip = ops.conv1x1_lp(fused, agg.redir[0].weight, lp, scale=sc, shift=sh, slope=1.0)
+        sc, sh = aff(agg.conv3[1])
+        out = ops.deconv3d_lp(c2, agg.conv3[0].weight, lp, sc, sh, 0.0, res_pre=skip, res_post=res_post)
+        return prob_volume.unsqueeze(1), out
+
     def forward(self, cost_volume, downsample=True, res_post=None):
+        if cost_volume.dtype != torch.float32:
+            if not downsample:
+                raise NotImplementedError("reduced-precision path: only the down-sampling form used by GwcNet")
+            return self._forward_lp(cost_volume, res_post)
         if downsample:
             cost_down = self.downsample(cost_volume)
             prob_volume = self.classify(cost_down).squeeze(1)

@@ -12,6 +12,17 @@ from .submodule import (BasicBlock, ConvBnReLU3d, ConvBn3d, Guidance, Propgation
 ops = _ensure().ops
 
 
+class _Features(dict):
+    """The extractor's result: `gwc_segments` = (l2, l3, l4), which the fused cost-volume kernel reads in place, and the
+    reference's `gwc_feature` = torch.cat((l2, l3, l4), 1) (gwcnet_dca_g.py:60) built only if somebody asks for it."""
+
+    def __missing__(self, key):
+        if key != "gwc_feature":
+            raise KeyError(key)
+        self[key] = torch.cat(self["gwc_segments"], dim=1)
+        return self[key]
+
+
 class feature_extraction(nn.Module):
     """reference gwcnet_dca_g.py:13-66 -- 2D backbone, caller of the hot path (stays on PyTorch-ROCm)."""
 
@@ -48,10 +59,10 @@ class feature_extraction(nn.Module):
         l2 = self.layer2(x)
         l3 = self.layer3(l2)
         l4 = self.layer4(l3)
-        gwc_feature = torch.cat((l2, l3, l4), dim=1)
-        if not self.concat_feature:
-            return {"gwc_feature": gwc_feature}
-        return {"gwc_feature": gwc_feature, "concat_feature": self.lastconv(gwc_feature)}
+        out = _Features(gwc_segments=(l2, l3, l4))
+        if self.concat_feature:
+            out["concat_feature"] = self.lastconv(out["gwc_feature"])
+        return out
 
 
 class _Dres0(nn.Sequential):
@@ -125,9 +136,15 @@ class GwcNet(nn.Module):
         """reference gwcnet_dca_g.py:216-239 (+ :244-275 when training).  Returns a dict with `pred4_q`
         (B,1,H/4,W/4) in 1/4-res pixels, `prob_volume2` and, in training mode, the auxiliary heads."""
         d = self.maxdisp // 4
-        volume = build_gwc_volume(gwc_left, gwc_right, d, self.num_groups)
-        if self.use_concat_volume:
-            volume = torch.cat((volume, build_concat_volume(concat_left, concat_right, d)), 1)
+        lp = ops._lp_dtype()
+        if lp is not None and (self.training or torch.is_grad_enabled()):
+            raise RuntimeError("ops.reduced_precision is inference only: call the model in eval mode under torch.no_grad()")
+        # gwc (+ concat) volume in ONE tensor, from the extractor's l2/l3/l4 maps in place when they are handed over as
+        # a tuple (no torch.cat of the features, no torch.cat of the two volumes: gwcnet_dca_g.py:60,217-220)
+        volume = ops.cost_volume(gwc_left, gwc_right, d, self.num_groups,
+                                 concat_left if self.use_concat_volume else None,
+                                 concat_right if self.use_concat_volume else None,
+                                 out_dtype=torch.float32 if lp is None else lp)
         cost0 = self.dres0(volume)
         cost0 = self.dres1(cost0)                               # dres1(cost0) + cost0
         prob_volume1, out1 = self.cva1(cost0, res_post=cost0)   # cost0 + augmented_cost
@@ -148,7 +165,7 @@ class GwcNet(nn.Module):
         features_left = self.feature_extraction(left)
         features_right = self.feature_extraction(right)
         guidance = self.guidance(left)
-        r = self.hot_path(features_left["gwc_feature"], features_right["gwc_feature"],
+        r = self.hot_path(features_left["gwc_segments"], features_right["gwc_segments"],
                           features_left.get("concat_feature"), features_right.get("concat_feature"))
         pred4 = self.prop(guidance["g"], r["pred4_q"])
         if self.training:

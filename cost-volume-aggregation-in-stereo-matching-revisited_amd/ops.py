@@ -117,6 +117,79 @@ def gwc_volume(ref, tgt, maxdisp, num_groups):
     return _GwcVolume.apply(ref, tgt, int(maxdisp), int(num_groups))
 
 
+class _CostVolume(torch.autograd.Function):
+    """Fused builder (csrc/volume_fused.hip): gwc volume from 1-3 channel segments per side + optional concat volume,
+    one output tensor, fp32 or the reduced-precision storage type."""
+
+    @staticmethod
+    def forward(ctx, maxdisp, num_groups, out_dtype, nseg, has_concat, *tensors):
+        refs = [_req(t, "cost_volume.ref") for t in tensors[:nseg]]
+        tgts = [_req(t, "cost_volume.tgt") for t in tensors[nseg:2 * nseg]]
+        cref = _req(tensors[2 * nseg], "cost_volume.cref") if has_concat else None
+        ctgt = _req(tensors[2 * nseg + 1], "cost_volume.ctgt") if has_concat else None
+        B, _, H, W = refs[0].shape
+        segC = [t.shape[1] for t in refs]
+        Cc = cref.shape[1] if has_concat else 0
+        for r_, t_ in zip(refs, tgts):
+            assert r_.shape == t_.shape and r_.shape[0] == B and tuple(r_.shape[2:]) == (H, W)
+        vol = torch.empty((B, num_groups + 2 * Cc, maxdisp, H, W), device=refs[0].device, dtype=out_dtype)
+        rp = (ctypes.c_void_p * nseg)(*[t.data_ptr() for t in refs])
+        tp = (ctypes.c_void_p * nseg)(*[t.data_ptr() for t in tgts])
+        sc = (ctypes.c_int * nseg)(*segC)
+        code = 0 if out_dtype == torch.float32 else LP_DTYPES[out_dtype]
+        with torch.cuda.device_of(vol):
+            _chk(_L().dca_cost_volume_fwd(rp, tp, sc, nseg, _ptr(cref), _ptr(ctgt), Cc, _ptr(vol), B, H, W, maxdisp,
+                                          num_groups, code, _stream()), "dca_cost_volume_fwd")
+        ctx.save_for_backward(*refs, *tgts)
+        ctx.meta = (maxdisp, num_groups, nseg, segC, Cc, (B, H, W))
+        return vol
+
+    @staticmethod
+    def backward(ctx, gvol):
+        maxdisp, G, nseg, segC, Cc, (B, H, W) = ctx.meta
+        refs, tgts = ctx.saved_tensors[:nseg], ctx.saved_tensors[nseg:]
+        gvol = _req(gvol, "cost_volume.backward")
+        ref = refs[0] if nseg == 1 else torch.cat(refs, 1)
+        tgt = tgts[0] if nseg == 1 else torch.cat(tgts, 1)
+        gg = gvol if Cc == 0 else gvol[:, :G].contiguous()
+        gref, gtgt = torch.empty_like(ref), torch.empty_like(tgt)
+        lib = _L()
+        with torch.cuda.device_of(gvol):
+            _chk(lib.dca_gwc_volume_bwd(_ptr(gg), _ptr(ref), _ptr(tgt), _ptr(gref), _ptr(gtgt), B, ref.shape[1], H, W,
+                                        maxdisp, G, _stream()), "dca_gwc_volume_bwd")
+            grads = list(gref.split(segC, 1)) + list(gtgt.split(segC, 1))
+            if Cc:
+                gc = gvol[:, G:].contiguous()
+                gcr = torch.empty((B, Cc, H, W), device=gvol.device, dtype=torch.float32)
+                gct = torch.empty_like(gcr)
+                _chk(lib.dca_concat_volume_bwd(_ptr(gc), _ptr(gcr), _ptr(gct), B, Cc, H, W, maxdisp, _stream()),
+                     "dca_concat_volume_bwd")
+                grads += [gcr, gct]
+        return (None, None, None, None, None) + tuple(grads)
+
+
+def cost_volume(ref, tgt, maxdisp, num_groups, cref=None, ctgt=None, out_dtype=torch.float32):
+    """build_gwc_volume(ref, tgt) [cat build_concat_volume(cref, ctgt)] as ONE (B, G + 2*Cc, D, H, W) tensor.  `ref` /
+    `tgt` may be tuples of channel segments (the extractor's l2 / l3 / l4 maps) that are read in place.  Falls back to
+    the separate builders + torch.cat when the fused kernel's alignment needs (W % 4, D % 4) are not met."""
+    refs = tuple(ref) if isinstance(ref, (tuple, list)) else (ref,)
+    tgts = tuple(tgt) if isinstance(tgt, (tuple, list)) else (tgt,)
+    W = refs[0].shape[-1]
+    C = sum(t.shape[1] for t in refs)
+    cpg = C // num_groups if num_groups else 0
+    ok = (W % 4 == 0 and maxdisp % 4 == 0 and len(refs) <= 3 and cpg in (1, 2, 4, 8, 16) and C % num_groups == 0
+          and all(t.shape[1] % cpg == 0 for t in refs))
+    if not ok:
+        if out_dtype != torch.float32:
+            raise RuntimeError("cost_volume: the reduced-precision volume needs W % 4 == 0 and maxdisp % 4 == 0")
+        r1 = refs[0] if len(refs) == 1 else torch.cat(refs, 1)
+        t1 = tgts[0] if len(tgts) == 1 else torch.cat(tgts, 1)
+        vol = gwc_volume(r1, t1, maxdisp, num_groups)
+        return vol if cref is None else torch.cat((vol, concat_volume(cref, ctgt, maxdisp)), 1)
+    extra = () if cref is None else (cref, ctgt)
+    return _CostVolume.apply(int(maxdisp), int(num_groups), out_dtype, len(refs), cref is not None, *refs, *tgts, *extra)
+
+
 def concat_volume(ref, tgt, maxdisp):
     return _ConcatVolume.apply(ref, tgt, int(maxdisp))
 
@@ -1031,4 +1104,80 @@ def conv1x1_lp(x, weight, lp, x2=None, scale=None, shift=None, slope=1.0, res_pr
         _chk(lib.dca_conv1_lp_forward(_ptr(x), _ptr(x2), _ptr(wf), _ptr(y), _ptr(_opt(scale, "scale")),
                                       _ptr(_opt(shift, "shift")), _ptr(res_pre), _ptr(res_post), float(slope), N, C1, C2,
                                       Cout, S, code, int(out_dtype == torch.float32), _stream()), "dca_conv1_lp_forward")
+    return y
+
+
+def _lp_code(t):
+    return LP_DTYPES[t.dtype]
+
+
+def avg_pool3d_lp(x):
+    """AvgPool3d(3, 2, 1) of a 2-byte (N,C,D,H,W) tensor -> fp32 (the 1/8-resolution interior of a DCA block is fp32)."""
+    x = _req_lp(x, "avg_pool3d_lp", x.dtype)
+    N, C, D, H, W = x.shape
+    y = torch.empty((N, C, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2), device=x.device, dtype=torch.float32)
+    with torch.cuda.device_of(x):
+        _chk(_L().dca_avgpool3d_lp_fwd(_ptr(x), _ptr(y), N * C, D, H, W, _lp_code(x), _stream()), "dca_avgpool3d_lp_fwd")
+    return y
+
+
+def trilinear_up2_lp(x, lp):
+    """x2 trilinear up-sampling of an fp32 tensor, written in the 2-byte type `lp`."""
+    x = _req(x, "trilinear_up2_lp")
+    N, C, D, H, W = x.shape
+    y = torch.empty((N, C, 2 * D, 2 * H, 2 * W), device=x.device, dtype=lp)
+    with torch.cuda.device_of(x):
+        _chk(_L().dca_trilinear_up2_lp_fwd(_ptr(x), _ptr(y), N * C, D, H, W, LP_DTYPES[lp], _stream()),
+             "dca_trilinear_up2_lp_fwd")
+    return y
+
+
+def conv3d_s2_lp(x, weight, scale, shift, slope):
+    """3x3x3 stride-2 conv + folded BN + activation reading a 2-byte x, fp32 result (exact-fp32 MFMA arithmetic)."""
+    x = _req_lp(x, "conv3d_s2_lp", x.dtype)
+    weight = _req(weight, "conv3d_s2_lp.weight")
+    N, Cin, D, H, W = x.shape
+    Cout = weight.shape[0]
+    Do, Ho, Wo = (D + 1) // 2, (H + 1) // 2, (W + 1) // 2
+    with torch.cuda.device_of(x):
+        wt, Apad = _prep_weight(weight, Cin, Cout, 27, 0, 0, 3, 2, False)
+        y = torch.empty((N, Cout, Do, Ho, Wo), device=x.device, dtype=torch.float32)
+        _chk(_L().dca_conv3d_forward_mixed(_ptr(x), _ptr(wt), _ptr(y), _ptr(scale), _ptr(shift), None, None, float(slope),
+                                           N, Cin, Cout, Apad, D, H, W, Do, Ho, Wo, 0, _lp_code(x), _stream()),
+             "dca_conv3d_forward_mixed")
+    return y
+
+
+def deconv3d_lp(x, weight, lp, scale, shift, slope, res_pre=None, res_post=None):
+    """ConvTranspose3d(3, s2, p1, op1) + folded BN + residuals + activation: fp32 x -> 2-byte result / residuals."""
+    x = _req(x, "deconv3d_lp")
+    weight = _req(weight, "deconv3d_lp.weight")
+    N, Cin, D, H, W = x.shape
+    Cout = weight.shape[1]
+    oshape = (N, Cout, 2 * D, 2 * H, 2 * W)
+    for r in (res_pre, res_post):
+        if r is not None and (r.dtype != lp or tuple(r.shape) != oshape):
+            raise RuntimeError("deconv3d_lp: residuals must have the output's shape and dtype")
+    res_pre = None if res_pre is None else _req_lp(res_pre, "deconv3d_lp.res_pre", lp)
+    res_post = None if res_post is None else _req_lp(res_post, "deconv3d_lp.res_post", lp)
+    with torch.cuda.device_of(x):
+        wt, Apad = _prep_weight(weight, Cin, Cout, 27, 1, 0, 3, 2, True)
+        y = torch.empty(oshape, device=x.device, dtype=lp)
+        _chk(_L().dca_conv3d_forward_mixed(_ptr(x), _ptr(wt), _ptr(y), _ptr(scale), _ptr(shift), _ptr(res_pre),
+                                           _ptr(res_post), float(slope), N, Cin, Cout, Apad, D, H, W, 2 * D, 2 * H, 2 * W, 1,
+                                           LP_DTYPES[lp], _stream()), "dca_conv3d_forward_mixed")
+    return y
+
+
+def conv3d_c1_lp(x, weight):
+    """nn.Conv3d(C, 1, 3, padding=1, bias=False) logit head on a 2-byte x: the 27 taps become the output axis of the
+    reduced-precision 1x1x1 GEMM (fp32 accumulation, fp32 tap tensor), then the fp32 27-tap shifted gather."""
+    lp = x.dtype
+    weight = _req(weight, "conv3d_c1_lp.weight")
+    N, C, D, H, W = x.shape
+    w27 = _memo(("c1lp",), (weight,), lambda: weight[0].reshape(C, 27).t().contiguous())
+    T = conv1x1_lp(x, w27, lp, out_dtype=torch.float32)
+    y = torch.empty((N, 1, D, H, W), device=x.device, dtype=torch.float32)
+    with torch.cuda.device_of(x):
+        _chk(_L().dca_conv3d_c1_gather(_ptr(T), _ptr(y), N, D, H, W, _stream()), "dca_conv3d_c1_gather")
     return y

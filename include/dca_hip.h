@@ -23,8 +23,12 @@ extern "C" {
 
 /* Bumped whenever an argument list below changes; the ctypes loader (_lib.py) refuses a library built from another
  * version of this header. */
-#define DCA_ABI_VERSION 2
+#define DCA_ABI_VERSION 3
 int dca_abi_version(void);
+
+/* storage types of the reduced-precision inference path (0 = fp32) */
+#define DCA_BF16 1
+#define DCA_FP16 2
 
 /* ---- cost volumes ------------------------------------------------------------------------------
  * build_gwc_volume(refimg_fea, targetimg_fea, maxdisp, num_groups)  models/submodule.py:157-167
@@ -39,6 +43,17 @@ int dca_concat_volume_fwd(const float* ref, const float* tgt, float* vol, int B,
                           hipStream_t stream);
 int dca_concat_volume_bwd(const float* gvol, float* gref, float* gtgt, int B, int C, int H, int W, int maxdisp,
                           hipStream_t stream);
+
+/* Fused builder (volume_fused.hip): gwc volume and, when Cc > 0, the concat volume written into ONE tensor
+ * vol (B, num_groups + 2*Cc, maxdisp, H, W) -- no torch.cat((gwc_volume, concat_volume), 1) (models/gwcnet_dca_g.py:217-220)
+ * -- from `nseg` (1..3) channel segments of the correlation features: refs[s], tgts[s]: (B, seg_channels[s], H, W), read
+ * in place instead of their concatenation gwc_feature = torch.cat((l2, l3, l4), 1) (gwcnet_dca_g.py:60).  refs / tgts /
+ * seg_channels are HOST arrays.  cref, ctgt: (B, Cc, H, W) or NULL.  dtype: 0 = fp32 volume, DCA_BF16 / DCA_FP16 = the
+ * reduced-precision inference path's storage type.  W % 4 == 0, maxdisp % 4 == 0, 16-byte aligned tensors; every
+ * segment width must be a multiple of channels / num_groups. */
+int dca_cost_volume_fwd(const float* const* refs, const float* const* tgts, const int* seg_channels, int nseg,
+                        const float* cref, const float* ctgt, int Cc, void* vol, int B, int H, int W, int maxdisp,
+                        int num_groups, int dtype, hipStream_t stream);
 
 /* ---- softmax over dim 1 / disparity_regression ---------------------------------------------------
  * x: (B,K,HW).  mode 0: out (B,K,HW) = F.softmax(x, dim=1)   (models/gwcnet_dca_g.py:238,248,...)
@@ -210,8 +225,6 @@ int dca_focal_loss_bwd(const float* const* ests, float* const* gests, const floa
 /* ---- reduced-precision inference path (BASELINE configs 2 "bf16" and 5 "fp16") ---------------------------------
  * Activations stored as bf16 / fp16, ONE native MFMA product per multiply, fp32 accumulation and fp32 epilogue
  * arithmetic (folded BatchNorm affine, activation, residuals); forward only.  dtype codes: */
-#define DCA_BF16 1
-#define DCA_FP16 2
 /* 3x3x3 stride-1 convolution (convbn_3d + ReLU of models/submodule.py:121-124 in eval mode).  wx: dca_conv3d_lp_weight_bytes
  * bytes, filled by dca_conv3d_lp_prep_weight (A, B, src_ab, flip as in dca_conv3d_prep_weight).  x: (N,Cin,D,H,W) in the
  * 2-byte type, or fp32 when in_f32; y, res_pre, res_post: (N,Cout,D,H,W) in the 2-byte type, or fp32 when out_f32.
@@ -232,6 +245,19 @@ int dca_conv1_lp_prep_weight(const float* w, void* wfrag, int Cout, int C1, int 
 int dca_conv1_lp_forward(const void* x, const void* x2, const void* wfrag, void* y, const float* scale,
                          const float* shift, const void* res_pre, const void* res_post, float slope, int N, int C1,
                          int C2, int Cout, long S, int dtype, int out_f32, hipStream_t stream);
+
+/* Mixed-storage forms of dca_conv3d_forward (exact-fp32 MFMA arithmetic, wt as for dca_conv3d_forward with Bpad 64 /
+ * 32): transposed == 0: 3x3x3 stride-2 conv, x (N,Cin,Di,Hi,Wi) 2-byte -> y (N,Cout<=64,Do,Ho,Wo) fp32, no residuals
+ * (cost_agg.conv1, models/augment/cva.py:16-17); transposed == 1: ConvTranspose3d(3,s2,p1,op1), x fp32 -> y, res_pre,
+ * res_post (N,Cout<=32,2Di,2Hi,2Wi) 2-byte (cost_agg.conv3 + ReLU(. + redir(x)) [+ outer residual], cva.py:21-29). */
+int dca_conv3d_forward_mixed(const void* x, const float* wt, void* y, const float* scale, const float* shift,
+                             const void* res_pre, const void* res_post, float slope, int N, int Cin, int Cout, int CinPad,
+                             int Di, int Hi, int Wi, int Do, int Ho, int Wo, int transposed, int dtype,
+                             hipStream_t stream);
+/* nn.AvgPool3d((3,3,3), 2, 1) (cva.py:39): x (NC,Di,Hi,Wi) 2-byte -> y (NC,ceil/2...) fp32; Wi % 4 == 0.
+ * F.interpolate(scale_factor=(2,2,2), mode='trilinear') (cva.py:64): x (NC,Di,Hi,Wi) fp32 -> y (NC,2Di,2Hi,2Wi) 2-byte. */
+int dca_avgpool3d_lp_fwd(const void* x, float* y, long NC, int Di, int Hi, int Wi, int dtype, hipStream_t stream);
+int dca_trilinear_up2_lp_fwd(const float* x, void* y, long NC, int Di, int Hi, int Wi, int dtype, hipStream_t stream);
 
 #ifdef __cplusplus
 }
