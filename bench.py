@@ -102,6 +102,7 @@ def eval_step(m, fL, fR, guid):
 
 
 
+PMC_FILE = "r02_pmc_traffic.json"       # written by tools/pmc_collect.sh + tools/pmc_summarise.py (separate --pmc passes)
 PEAK_BF16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
 PEAK_HBM_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 # algorithmic work of the eval forward at 544x960 / D=192 (G variant), fp32
@@ -110,7 +111,7 @@ PATH_FWD_GFLOP, PATH_FWD_GB = 822.0, 10.71
 PATH_FB_GFLOP, PATH_FB_GB = 3 * (822.0 + 3 * 89.3), 3 * (2676.7 + 870.0) * 4e-3
 
 
-def kernel_roofline(device):
+def kernel_roofline(device, dtype="f32"):
     """Dominant kernels timed live with HIP events on the launch stream (torch's current stream is the stream the
     C ABI launches on), all on the 3x3x3 32->32 convolution at 1/4 resolution (dres0/1, classif*, the cva blocks and
     every stride-1 backward-data pass) and its weight gradient.  `achieved` is always ALGORITHMIC fp32 FLOP/s
@@ -137,6 +138,16 @@ def kernel_roofline(device):
                                                32, 32, d, h, w, ops._stream()), "x3 forward")
 
         cases = []
+        if dtype != "f32":
+            # reduced-precision run: its dominant kernel is conv3_lp_kernel on 2-byte tensors.  86.6 GFLOP over 200.6 MB
+            # = 432 FLOP/B > the 312 FLOP/B ridge (2.5 PFLOP/s / 8 TB/s): matrix-pipe bound on paper, so `frac` is against
+            # the dense bf16 / fp16 MFMA peak; the HBM view of the same launch is given beside it.
+            lp = torch.bfloat16 if dtype == "bf16" else torch.float16
+            xl = x.to(lp)
+            sc_, sh_ = torch.ones(32, device=device), torch.zeros(32, device=device)
+            cases.append((f"conv3_lp_kernel<{dtype}> (3x3x3 32->32 @1/4 res, {dtype} storage in and out, one MFMA product per "
+                          "multiply, fp32 accumulation, fused affine + ReLU epilogue)", "conv3_lp", PEAK_BF16_MFMA_TFLOPS,
+                          lambda: ops.conv3d_lp(xl, wgt, lp, sc_, sh_, 0.0)))
         if ops.CONV_X3:
             cases.append(("conv3_bf16x3_kernel (3x3x3 32->32 @1/4 res; fp32 via exact 3-way bf16 split, 6 bf16 MFMA "
                           "products per fp32 product)", "conv3_bf16x3", PEAK_BF16_MFMA_TFLOPS / 6.0, run_x3))
@@ -160,8 +171,8 @@ def kernel_roofline(device):
         # the cost-volume builder itself is bandwidth bound: 4*(2*320*hw + 40*V4) algorithmic bytes per launch
         fl, fr = torch.randn(1, 320, h, w, device=device), torch.randn(1, 320, h, w, device=device)
         gwc_bytes = 4.0 * (2 * 320 * h * w + 40 * d * h * w)
-        cases.append(("gwc_fwd_kernel<8> (build_gwc_volume, 40 groups x %d disparities @1/4 res)" % d, None, None,
-                      lambda: ops.gwc_volume(fl, fr, d, 40)))
+        cases.append(("gwc_fused_kernel<8> (build_gwc_volume, 40 groups x %d disparities @1/4 res, fp32 volume)" % d, None,
+                      None, lambda: ops.cost_volume(fl, fr, d, 40)))
         for name, key, peak, fn in cases:
             for _ in range(2):
                 fn()
@@ -184,6 +195,11 @@ def kernel_roofline(device):
             out[name] = {"bound": "mfma", "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(tf / peak, 4), "traffic": None, "ms_per_launch": round(ms, 4),
                          "flop_per_launch": flops, "pmc_key": key}
+            if key == "conv3_lp":
+                lp_bytes = 2.0 * 2 * 32 * d * h * w
+                out[name]["algorithmic_bytes"] = lp_bytes
+                out[name]["hbm_view"] = {"achieved": round(lp_bytes / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
+                                         "unit": "GB/s", "frac": round(lp_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
             if key in ("conv3_bf16x3", "wgrad3_bf16x3"):
                 out[name]["peak_note"] = "dense bf16 MFMA peak (2500) / 6 products per fp32 product"
                 out[name]["executed_bf16"] = {"achieved": round(6 * tf, 1), "peak": PEAK_BF16_MFMA_TFLOPS,
@@ -424,11 +440,11 @@ def main():
                        (f"every step, {prepack_n} layouts in one launch (ops.PrepackPlan)" if prepack_n else
                         "every step, one launch per layout")},
         }
-        roof = kernel_roofline(device) if not args.shape else {}
+        roof = kernel_roofline(device, args.dtype) if not args.shape else {}
         names = list(roof)
         # HBM bytes per launch from the PMC passes committed under profiles/ (cannot be collected inside this run)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
             for n in names:
                 key = roof[n].pop("pmc_key", None)
                 if key in pmc:

@@ -12,23 +12,28 @@
 #include "../../include/dca_hip.h"
 
 // ------------------------------------------------------------------------------------ BN statistics
-// part[(c*nchunk + chunk)*2 + {0,1}] = (sum x, sum x^2) over all samples and one chunk of S (double).
+// part[(c*nchunk + chunk)*2 + {0,1}] = (sum (x-K), sum (x-K)^2) over all samples and one chunk of S (double), with the
+// per-channel shift K = x[0, c, 0] stored at part[C*nchunk*2 + c]: E[(x-K)^2] - E[x-K]^2 does not cancel
+// catastrophically when |mean| >> std (the raw E[x^2] - mean^2 loses (mean/std)^2 * 1e-7 of the variance in fp32).
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, double* __restrict__ part, int N,
                                                        int C, long S, int nchunk, long chunk_len, int vec) {
   const int c = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
   const long s0 = ch * chunk_len, s1 = min(S, s0 + chunk_len);
+  const float K = x[(long)c * S];
+  if (ch == 0 && tid == 0) part[(long)C * nchunk * 2 + c] = (double)K;
   float s = 0.f, ss = 0.f;
   for (int n = 0; n < N; ++n) {
     const float* p = x + ((long)n * C + c) * S;
     if (vec) {
       for (long i = s0 + 4 * tid; i < s1; i += 1024) {
-        const float4 v = *(const float4*)(p + i);
+        float4 v = *(const float4*)(p + i);
+        v.x -= K; v.y -= K; v.z -= K; v.w -= K;
         s += (v.x + v.y) + (v.z + v.w);
         ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
       }
     } else {
       for (long i = s0 + tid; i < s1; i += 256) {
-        const float v = p[i];
+        const float v = p[i] - K;
         s += v;
         ss += v * v;
       }
@@ -60,9 +65,10 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const double* __restric
     }
     s = wave_sum_d(s);
     ss = wave_sum_d(ss);
-    const double m = s / count;
-    double v = ss / count - m * m;
+    const double ms = s / count;                       // mean of (x - K)
+    double v = ss / count - ms * ms;
     if (v < 0.0) v = 0.0;
+    const double m = part[(long)C * nchunk * 2 + c] + ms;
     mean = (float)m;
     var = (float)v;
     if (running_mean && lane == 0) {

@@ -534,7 +534,7 @@ def bn_stats_vector(y, gamma, beta, running_mean, running_var, training, momentu
     lib = _L()
     if training:
         nchunk = lib.dca_bn_num_chunks(C, S)
-        part = torch.empty((C * nchunk * 2,), device=y.device, dtype=torch.float64)
+        part = torch.empty((C * nchunk * 2 + C,), device=y.device, dtype=torch.float64)   # partial sums + C shifts
         _chk(lib.dca_bn_stats(_ptr(y), _ptr(part), N, C, S, _stream()), "dca_bn_stats")
         _chk(lib.dca_bn_finalize(_ptr(part), nchunk, float(N * S), _ptr(gamma), _ptr(beta), _ptr(running_mean),
                                  _ptr(running_var), float(momentum), float(eps), 1, _ptr(stats), C, _stream()),

@@ -23,7 +23,7 @@ extern "C" {
 
 /* Bumped whenever an argument list below changes; the ctypes loader (_lib.py) refuses a library built from another
  * version of this header. */
-#define DCA_ABI_VERSION 3
+#define DCA_ABI_VERSION 4
 int dca_abi_version(void);
 
 /* storage types of the reduced-precision inference path (0 = fp32) */
@@ -156,8 +156,9 @@ int dca_conv3d_c1_bwd_data(const float* dy, const float* w, float* dx, int N, in
 
 /* ---- BatchNorm3d + activation + residual -------------------------------------------------------------
  * nn.BatchNorm3d defaults (eps 1e-5, momentum 0.1) as used by convbn_3d, models/submodule.py:121-124.
- * dca_bn_stats:    part[(c*nchunk+i)*2+{0,1}] = partial (sum, sum of squares) in double;
- *                  nchunk = dca_bn_num_chunks(C, S).
+ * dca_bn_stats:    part[(c*nchunk+i)*2+{0,1}] = partial (sum, sum of squares) of x - K_c in double, with the per-channel
+ *                  shift K_c = x[0,c,0] at part[C*nchunk*2 + c] (no catastrophic cancellation when |mean| >> std);
+ *                  nchunk = dca_bn_num_chunks(C, S); part holds C*nchunk*2 + C doubles.
  * dca_bn_finalize: stats = [mean | invstd | scale | shift] (4*C floats); training != 0 uses the batch
  *                  statistics and updates running_mean/var (unbiased), else uses the running stats.
  * dca_bn_apply:    z = act(scale*y + shift + res_pre) + res_post.

@@ -369,6 +369,25 @@ def test_bn_act(training, slope, pre, post, shape):
     assert int(bn.num_batches_tracked) == (1 if training else 0)
 
 
+def test_bn_statistics_survive_a_large_mean():
+    """|mean| / std ~ 1e3 per channel: E[x^2] - mean^2 in fp32 would lose ~10 % of the variance; the shifted
+    sums keep train-mode BatchNorm at fp32 accuracy (the reference's ATen kernel is a two-pass / Welford form)."""
+    _, ops = _mods()
+    torch.manual_seed(3)
+    y = torch.randn(2, 32, 6, 20, 36) * torch.rand(1, 32, 1, 1, 1).add(0.5) + torch.randn(1, 32, 1, 1, 1) * 1000.0
+    bn = torch.nn.BatchNorm3d(32)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_()
+    ref_bn = torch.nn.BatchNorm3d(32)
+    ref_bn.load_state_dict(bn.state_dict())
+    ref = torch.nn.functional.relu(ref_bn.double()(y.double()))
+    bn = bn.to(DEV).train()
+    got = ops.bn_act(y.to(DEV), bn, 0.0)
+    close(got, ref, 2e-4, "train-mode BN + ReLU with mean/std ~ 1e3")     # fp32 input rounding alone is ~1e3 * 6e-8 / std
+    close(bn.running_var, ref_bn.running_var, 1e-4, "running_var")
+    close(bn.running_mean, ref_bn.running_mean, 1e-6, "running_mean")
+
+
 def test_convbn_fused_inference_matches_unfused():
     _, ops = _mods()
     from dcanet_amd.models.submodule import ConvBn3d

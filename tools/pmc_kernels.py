@@ -1,47 +1,74 @@
-"""Launches the dominant kernels a few times at the BASELINE shape (for rocprofv3 --pmc passes).
-    rocprofv3 --pmc FETCH_SIZE --output-format csv -d out -- python tools/pmc_kernels.py
-    rocprofv3 --pmc WRITE_SIZE --output-format csv -d out -- python tools/pmc_kernels.py
-then `python tools/pmc_kernels.py --summarise fetch.csv write.csv` folds the two counter_collection.csv files into
-profiles/r01_pmc_traffic.json (per-launch averages; HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB, the gfx950
-correction of MI355X_MICROARCH.md's HBM section)."""
+"""PMC evidence for the dominant kernels at the BASELINE shape (companion of bench.py's `roofline.traffic`).
+
+Collect (on the GPU box; separate --pmc passes -- FETCH_SIZE and WRITE_SIZE do not fit one pass, and gpurun refuses
+--pmc together with the trace domains):
+    tools/pmc_collect.sh          # three rocprofv3 passes over this script -> gpurun_out/pmc_r02_{fetch,write,sq}
+then fold them into profiles/r02_pmc_traffic.json (the file bench.py reads), with the commit they were taken at:
+    python tools/pmc_kernels.py --summarise gpurun_out/pmc_r02_fetch gpurun_out/pmc_r02_write gpurun_out/pmc_r02_sq
+
+HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB: gfx950's FETCH_SIZE tallies 128-byte requests at 64 bytes
+(MI355X_MICROARCH.md, HBM section; exact for 16-byte-per-lane streams, other access widths are uncalibrated).
+MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES x 4 SIMDs-per-CU-normalisation as reported)."""
 import csv
+import glob
 import json
 import os
+import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-KEYS = {"conv3_bf16x3_kernel": "conv3_bf16x3", "wgrad3_bf16x3_kernel": "wgrad3_bf16x3", "conv3_mfma_kernel<1, 1, 8, 4, 8, 16, true>": "conv3_mfma",
-        "wgrad3_kernel<1, 16>": "wgrad3"}
-ALGO_BYTES = 2 * 32 * 48 * 136 * 240 * 4 + 27 * 32 * 32 * 4   # read x + write y (or read x, dy) + weights
+V4 = 48 * 136 * 240
+KEYS = {   # substring of the kernel name -> (key, algorithmic bytes per launch)
+    "conv3_bf16x3_kernel": ("conv3_bf16x3", 2 * 32 * V4 * 4 + 27 * 32 * 32 * 4),
+    "wgrad3_bf16x3_kernel": ("wgrad3_bf16x3", 2 * 32 * V4 * 4 + 27 * 32 * 32 * 4),
+    "conv3_mfma_kernel<1, 1, 8, 4, 8, 16, true": ("conv3_mfma", 2 * 32 * V4 * 4 + 27 * 32 * 32 * 4),
+    "wgrad3_kernel<1, 16>": ("wgrad3", 2 * 32 * V4 * 4 + 27 * 32 * 32 * 4),
+    "conv3_lp_kernelIDF16bLb0ELb0ELb1ELi1": ("conv3_lp", 2 * 32 * V4 * 2 + 27 * 32 * 32 * 2),
+    "gwc_fused_kernelILi8Ef": ("gwc_fused", 4 * (2 * 320 * 136 * 240 + 40 * V4)),
+}
 
 
-def summarise(fetch_csv, write_csv):
+def _rows(directory):
+    for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        yield from csv.DictReader(open(path))
+
+
+def summarise(fetch_dir, write_dir, sq_dir):
     acc = {}
-    for path, col in ((fetch_csv, "FETCH_SIZE"), (write_csv, "WRITE_SIZE")):
-        for r in csv.DictReader(open(path)):
-            if r["Counter_Name"] != col:
-                continue
-            for pat, key in KEYS.items():
+    for d in (fetch_dir, write_dir, sq_dir):
+        for r in _rows(d):
+            for pat, (key, algo) in KEYS.items():
                 if pat in r["Kernel_Name"]:
-                    acc.setdefault(key, {}).setdefault(col, []).append(float(r["Counter_Value"]))
-                    acc[key]["kernel"] = r["Kernel_Name"].split("(")[0]
-    out = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-    for key, v in acc.items():
-        f = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"])
-        w = sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])
-        out[key] = {"FETCH_SIZE_KiB": round(f, 2), "WRITE_SIZE_KiB": round(w, 2),
-                    "hbm_bytes_per_launch": (2 * f + w) * 1024, "algorithmic_bytes": ALGO_BYTES, "kernel": v["kernel"],
-                    "launches": len(v["FETCH_SIZE"])}
-    json.dump(out, open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"), "w"), indent=1)
+                    e = acc.setdefault(key, {"algorithmic_bytes": algo, "kernel": r["Kernel_Name"].split("(")[0][:80]})
+                    e.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+    out = {"_how": __doc__.split("\n\n")[1].strip(), "_commit": head}
+    for key, e in acc.items():
+        mean = lambda k: (sum(e[k]) / len(e[k])) if k in e else None
+        f, w = mean("FETCH_SIZE"), mean("WRITE_SIZE")
+        o = {"kernel": e["kernel"], "algorithmic_bytes": e["algorithmic_bytes"], "launches": len(e.get("FETCH_SIZE", []))}
+        if f is not None and w is not None:
+            o.update(FETCH_SIZE_KiB=round(f, 1), WRITE_SIZE_KiB=round(w, 1), hbm_bytes_per_launch=(2 * f + w) * 1024,
+                     traffic_over_algorithmic=round((2 * f + w) * 1024 / e["algorithmic_bytes"], 3))
+        for k in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU",
+                  "SQ_INSTS_MFMA", "SQ_INSTS_LDS", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE"):
+            if mean(k) is not None:
+                o[k] = round(mean(k), 1)
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in o and "GRBM_GUI_ACTIVE" in o and o["GRBM_GUI_ACTIVE"] > 0:
+            # MFMA-busy cycles are summed over all SIMDs of the chip (256 CUs x 4); GRBM_GUI_ACTIVE = kernel cycles
+            o["mfma_busy_frac"] = round(o["SQ_VALU_MFMA_BUSY_CYCLES"] / (o["GRBM_GUI_ACTIVE"] * 256 * 4), 4)
+        out[key] = o
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--summarise":
-        summarise(sys.argv[2], sys.argv[3])
+        summarise(*sys.argv[2:5])
     else:
         import torch
         import bench
-        print(bench.kernel_roofline(torch.device("cuda", 0)))
+        print(json.dumps(bench.kernel_roofline(torch.device("cuda", 0), "bf16"))[:400])
