@@ -8,7 +8,8 @@ then fold them into profiles/r02_pmc_traffic.json (the file bench.py reads), wit
 
 HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB: gfx950's FETCH_SIZE tallies 128-byte requests at 64 bytes
 (MI355X_MICROARCH.md, HBM section; exact for 16-byte-per-lane streams, other access widths are uncalibrated).
-MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES x 4 SIMDs-per-CU-normalisation as reported)."""
+MFMA utilisation (`mfma_busy_frac`) = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), kernel cycles =
+GRBM_GUI_ACTIVE / 8 XCDs: the share of matrix-pipe cycles that are busy AT THE CLOCK THE CHIP ACTUALLY HELD."""
 import csv
 import glob
 import json
@@ -26,7 +27,7 @@ KEYS = {   # substring of the kernel name -> (key, algorithmic bytes per launch)
     "conv3_mfma_kernel<1, 1, 8, 4, 8, 16, true": ("conv3_mfma", 2 * 32 * V4 * 4 + 27 * 32 * 32 * 4),
     "wgrad3_kernel<1, 16>": ("wgrad3", 2 * 32 * V4 * 4 + 27 * 32 * 32 * 4),
     "conv3_lp_kernelIDF16bLb0ELb0ELb1ELi1": ("conv3_lp", 2 * 32 * V4 * 2 + 27 * 32 * 32 * 2),
-    "gwc_fused_kernelILi8Ef": ("gwc_fused", 4 * (2 * 320 * 136 * 240 + 40 * V4)),
+    "gwc_fused_kernel<8, float>": ("gwc_fused", 4 * (2 * 320 * 136 * 240 + 40 * V4)),
 }
 
 
@@ -57,8 +58,11 @@ def summarise(fetch_dir, write_dir, sq_dir):
             if mean(k) is not None:
                 o[k] = round(mean(k), 1)
         if "SQ_VALU_MFMA_BUSY_CYCLES" in o and "GRBM_GUI_ACTIVE" in o and o["GRBM_GUI_ACTIVE"] > 0:
-            # MFMA-busy cycles are summed over all SIMDs of the chip (256 CUs x 4); GRBM_GUI_ACTIVE = kernel cycles
-            o["mfma_busy_frac"] = round(o["SQ_VALU_MFMA_BUSY_CYCLES"] / (o["GRBM_GUI_ACTIVE"] * 256 * 4), 4)
+            # SQ_VALU_MFMA_BUSY_CYCLES is summed over the chip's 1024 SIMDs (check: = 32 x SQ_INSTS_MFMA for 32x32x16
+            # bf16); GRBM_GUI_ACTIVE is summed over the 8 XCDs, so GUI_ACTIVE / 8 = the kernel's duration in shader cycles
+            cyc = o["GRBM_GUI_ACTIVE"] / 8.0
+            o["kernel_cycles"] = round(cyc, 1)
+            o["mfma_busy_frac"] = round(o["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024), 4)
         out[key] = o
     path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     json.dump(out, open(path, "w"), indent=1)
