@@ -11,9 +11,9 @@
 //  * stereo focal loss of one level -- StereoFocalLoss.loss_per_level with LaplaceDisp2Prob (models/loss.py:206-240,
 //    60-128): log_softmax of the estimate over the disparity axis, Laplace target softmax(-|k - gt|) of the (already
 //    pooled) ground truth, focal weight (1 - P)^-coef, validity masks, mean over ALL pixels.  The reference builds
-//    five (B,48,h,w) temporaries per level; here a thread owns one pixel, computes its target coefficients once (LDS
-//    column) for ALL levels of that resolution and writes one partial sum per workgroup and level (order-fixed
-//    reduction, no atomics).  The estimate handed in by GwcNet is already a
+//    five (B,48,h,w) temporaries per level; here a thread owns one pixel of one level, keeps its target coefficients
+//    in an LDS column, and one launch covers ALL levels of that resolution; one partial sum per workgroup and level
+//    (order-fixed reduction, no atomics).  The estimate handed in by GwcNet is already a
 //    softmax output and is log_softmax-ed again -- reproduced, not fixed.
 #include "dca_common.h"
 #include "../../include/dca_hip.h"
@@ -164,7 +164,7 @@ struct FocalArgs {
 };
 
 // part[(lev*B + b)*nblk + block] = sum over the block's pixels of  -sum_k P_k * log_softmax(est)_k * (1-P_k)^-coef * valid.
-// The target (P_k, focal weight) depends only on the ground truth, so it is computed once per pixel for all levels.
+// The target (P_k, focal weight) depends only on the ground truth; grid.z = level.
 template <int NT>
 __global__ __launch_bounds__(NT) void focal_fwd_kernel(FocalArgs a, const float* __restrict__ gt,
                                                         const int* __restrict__ any_valid_p, double* __restrict__ part,
@@ -182,7 +182,8 @@ __global__ __launch_bounds__(NT) void focal_fwd_kernel(FocalArgs a, const float*
       col[k * NT + tid] = p * focal_weight(p, coef) * t.valid;
     }
   }
-  for (int lev = 0; lev < a.nlev; ++lev) {
+  {
+    const int lev = blockIdx.z;     // one workgroup per (pixel block, batch, level): 5x the workgroups of a level loop
     float loss = 0.f;
     if (live) {
       const float* e = a.est[lev] + (long)b * K * HW + pix;
@@ -228,7 +229,8 @@ __global__ __launch_bounds__(NT) void focal_bwd_kernel(FocalArgs a, const float*
     col[k * NT + tid] = c;
     csum += c;
   }
-  for (int lev = 0; lev < a.nlev; ++lev) {
+  {
+    const int lev = blockIdx.z;
     const float gs = gout[0] * a.weight[lev] * inv_count;
     const float* e = a.est[lev] + (long)b * K * HW + pix;
     float* g = a.gest[lev] + (long)b * K * HW + pix;
@@ -313,10 +315,10 @@ extern "C" int dca_focal_loss_fwd(const float* const* ests, const float* weights
   int* flag = (int*)(work + (long)nlev * per_level);
   hipLaunchKernelGGL(focal_any_valid_kernel, dim3(1), dim3(256), 0, stream, gt, (long)B * HW, K, flag);
   if (nt == 256)
-    hipLaunchKernelGGL(focal_fwd_kernel<256>, dim3(nb, B), dim3(256), (size_t)K * 256 * sizeof(float), stream, a, gt,
+    hipLaunchKernelGGL(focal_fwd_kernel<256>, dim3(nb, B, nlev), dim3(256), (size_t)K * 256 * sizeof(float), stream, a, gt,
                        flag, work, K, HW, focal_coefficient);
   else
-    hipLaunchKernelGGL(focal_fwd_kernel<64>, dim3(nb, B), dim3(64), (size_t)K * 64 * sizeof(float), stream, a, gt, flag,
+    hipLaunchKernelGGL(focal_fwd_kernel<64>, dim3(nb, B, nlev), dim3(64), (size_t)K * 64 * sizeof(float), stream, a, gt, flag,
                        work, K, HW, focal_coefficient);
   hipLaunchKernelGGL(focal_finalize_kernel, dim3(1), dim3(64), 0, stream, a, work, per_level, (double)B * (double)HW,
                      out);
@@ -334,10 +336,10 @@ extern "C" int dca_focal_loss_bwd(const float* const* ests, float* const* gests,
   const int* flag = (const int*)(work + (long)nlev * per_level);
   const float inv_count = (float)(1.0 / ((double)B * (double)HW));
   if (nt == 256)
-    hipLaunchKernelGGL(focal_bwd_kernel<256>, dim3(nb, B), dim3(256), (size_t)K * 256 * sizeof(float), stream, a, gt,
+    hipLaunchKernelGGL(focal_bwd_kernel<256>, dim3(nb, B, nlev), dim3(256), (size_t)K * 256 * sizeof(float), stream, a, gt,
                        flag, gloss, K, HW, focal_coefficient, inv_count);
   else
-    hipLaunchKernelGGL(focal_bwd_kernel<64>, dim3(nb, B), dim3(64), (size_t)K * 64 * sizeof(float), stream, a, gt, flag,
+    hipLaunchKernelGGL(focal_bwd_kernel<64>, dim3(nb, B, nlev), dim3(64), (size_t)K * 64 * sizeof(float), stream, a, gt, flag,
                        gloss, K, HW, focal_coefficient, inv_count);
   return dca_launch_status();
 }
