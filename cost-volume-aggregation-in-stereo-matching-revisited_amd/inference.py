@@ -62,10 +62,13 @@ class KittiInference:
     weights loaded.  The 2D networks run as ordinary PyTorch-ROCm launches; the cost-volume path (volume -> dres0/1 ->
     3 x cva -> classif3 -> soft-argmin) is captured once for the fixed frame size and replayed (`graph=False`: eager)."""
 
-    def __init__(self, model, crop_height: int = 384, crop_width: int = 1248, graph: bool = True):
+    def __init__(self, model, crop_height: int = 384, crop_width: int = 1248, graph: bool = True, dtype=None):
+        """dtype: None (fp32) or torch.float16 / torch.bfloat16 -- the reduced-precision path of BASELINE config 5
+        ("fp16, hipGraph-captured 3D hourglass"): the captured hot path runs under ops.reduced_precision(dtype)."""
         self.net = model.module if isinstance(model, torch.nn.DataParallel) else model
         self.crop_height, self.crop_width = crop_height, crop_width
         self.graph = graph
+        self.dtype = dtype
         self._graphed = None
         self.net.eval()
 
@@ -78,12 +81,16 @@ class KittiInference:
         args = [fl["gwc_segments"], fr["gwc_segments"]]
         if net.use_concat_volume:
             args += [fl["concat_feature"], fr["concat_feature"]]
-        if self.graph:
-            if self._graphed is None:
-                self._graphed = GraphedHotPath(net, *args)
-            r = self._graphed(*args)
-        else:
-            r = net.hot_path(*args)
+        import contextlib
+        from . import ops
+        ctx = ops.reduced_precision(self.dtype) if self.dtype is not None else contextlib.nullcontext()
+        with ctx:      # (a replay needs no context: the captured launches are already the reduced-precision kernels)
+            if self.graph:
+                if self._graphed is None:
+                    self._graphed = GraphedHotPath(net, *args)
+                r = self._graphed(*args)
+            else:
+                r = net.hot_path(*args)
         return net.prop(guidance, r["pred4_q"])
 
     def __call__(self, left_rgb: np.ndarray, right_rgb: np.ndarray) -> np.ndarray:

@@ -168,3 +168,29 @@ def test_reduced_precision_is_inference_only():
             b = m.hot_path(fL, fL)["pred4_q"]
         c = m.hot_path(fL, fL)["pred4_q"]
     assert torch.equal(a, c) and not torch.equal(a, b)
+
+
+@pytest.mark.timeout(900)
+def test_config5_kitti_frame_fp16_hipgraph(capsys):
+    """BASELINE config 5: KITTI 384x1248 frame (quarter-res 96 x 312), D=192, fp16, the 3D part replayed from a hipGraph.
+    The replay must equal the eager reduced-precision run bit for bit, and pass the EPE gate against the fp32 CPU oracle."""
+    from oracle import dcanet_oracle as O
+    from dcanet_amd import ops
+    from dcanet_amd.graph import GraphedHotPath
+    m, sd = _seeded_model(192)
+    fL, fR = seeded_tensor("kitti.fL", (1, 320, 96, 312)), seeded_tensor("kitti.fR", (1, 320, 96, 312))
+    guid = seeded_tensor("kitti.guid", (1, 64, 96, 312))
+    gt = torch.rand(1, 1, 384, 1248, generator=torch.Generator().manual_seed(9)) * 190.0 + 1.0
+    with torch.no_grad():
+        ref = O.prop(sd, guid, O.hot_path(sd, fL, fR, 192, False)["pred4_q"], False)
+        with ops.reduced_precision(torch.float16):
+            eager = m.hot_path(fL.to(DEV), fR.to(DEV))["pred4_q"].clone()
+            g = GraphedHotPath(m, fL.to(DEV), fR.to(DEV))
+        replay = g(fL.to(DEV), fR.to(DEV))["pred4_q"]          # outside the context: the graph holds the fp16 kernels
+        assert torch.equal(replay, eager), f"replay differs by {(replay - eager).abs().max().item():.3e}"
+        full = m.prop(guid.to(DEV), replay).cpu()
+    epe = lambda x: (x - gt).abs().mean().item()
+    dev = (full - ref).abs()
+    with capsys.disabled():
+        print(f"\n[config 5, 384x1248 fp16 graph] |dEPE| {abs(epe(full) - epe(ref)):.2e}  mean|d| {dev.mean().item():.3e}  max|d| {dev.max().item():.3e}")
+    assert abs(epe(full) - epe(ref)) <= 1e-3 and dev.mean().item() <= 0.05
