@@ -1148,8 +1148,10 @@ def conv3d_s2_lp(x, weight, scale, shift, slope):
     return y
 
 
-def deconv3d_lp(x, weight, lp, scale, shift, slope, res_pre=None, res_post=None):
-    """ConvTranspose3d(3, s2, p1, op1) + folded BN + residuals + activation: fp32 x -> 2-byte result / residuals."""
+def deconv3d_lp(x, weight, lp, scale, shift, slope, res_pre=None, res_post=None, exact=False):
+    """ConvTranspose3d(3, s2, p1, op1) + folded BN + residuals + activation: fp32 x -> 2-byte result / residuals.
+    Default: operands rounded to `lp`, one MFMA product (csrc/deconv3d_lp.hip); exact=True keeps the fp32 MFMA
+    arithmetic and only writes / reads the 2-byte tensors (csrc/conv3d_mfma.hip)."""
     x = _req(x, "deconv3d_lp")
     weight = _req(weight, "deconv3d_lp.weight")
     N, Cin, D, H, W = x.shape
@@ -1160,12 +1162,26 @@ def deconv3d_lp(x, weight, lp, scale, shift, slope, res_pre=None, res_post=None)
             raise RuntimeError("deconv3d_lp: residuals must have the output's shape and dtype")
     res_pre = None if res_pre is None else _req_lp(res_pre, "deconv3d_lp.res_pre", lp)
     res_post = None if res_post is None else _req_lp(res_post, "deconv3d_lp.res_post", lp)
+    lib = _L()
+    code = LP_DTYPES[lp]
     with torch.cuda.device_of(x):
-        wt, Apad = _prep_weight(weight, Cin, Cout, 27, 1, 0, 3, 2, True)
         y = torch.empty(oshape, device=x.device, dtype=lp)
-        _chk(_L().dca_conv3d_forward_mixed(_ptr(x), _ptr(wt), _ptr(y), _ptr(scale), _ptr(shift), _ptr(res_pre),
-                                           _ptr(res_post), float(slope), N, Cin, Cout, Apad, D, H, W, 2 * D, 2 * H, 2 * W, 1,
-                                           LP_DTYPES[lp], _stream()), "dca_conv3d_forward_mixed")
+        if exact or Cin > 64 or Cout > 32:
+            wt, Apad = _prep_weight(weight, Cin, Cout, 27, 1, 0, 3, 2, True)
+            _chk(lib.dca_conv3d_forward_mixed(_ptr(x), _ptr(wt), _ptr(y), _ptr(scale), _ptr(shift), _ptr(res_pre),
+                                              _ptr(res_post), float(slope), N, Cin, Cout, Apad, D, H, W, 2 * D, 2 * H, 2 * W,
+                                              1, code, _stream()), "dca_conv3d_forward_mixed")
+            return y
+
+        def build():
+            wx = torch.empty((lib.dca_conv3d_lp_weight_bytes(Cin, Cout) // 2,), device=x.device, dtype=torch.int16)
+            _chk(lib.dca_conv3d_lp_prep_weight(_ptr(weight), _ptr(wx), Cin, Cout, 1, 0, code, _stream()),
+                 "dca_conv3d_lp_prep_weight")
+            return wx
+        wx = _memo(("lpdeconv", Cin, Cout, code), (weight,), build)
+        _chk(lib.dca_deconv3d_lp_forward(_ptr(x), _ptr(wx), _ptr(y), _ptr(_opt(scale, "scale")), _ptr(_opt(shift, "shift")),
+                                         _ptr(res_pre), _ptr(res_post), float(slope), N, Cin, Cout, D, H, W, code, _stream()),
+             "dca_deconv3d_lp_forward")
     return y
 
 

@@ -255,6 +255,12 @@ int dca_conv3d_forward_mixed(const void* x, const float* wt, void* y, const floa
                              const void* res_pre, const void* res_post, float slope, int N, int Cin, int Cout, int CinPad,
                              int Di, int Hi, int Wi, int Do, int Ho, int Wo, int transposed, int dtype,
                              hipStream_t stream);
+/* Reduced-precision ConvTranspose3d(3, s2, p1, op1) (deconv3d_lp.hip; cost_agg.conv3 + ReLU(. + redir) [+ outer residual],
+ * cva.py:21-29): x (N,Cin<=64,Di,Hi,Wi) fp32 rounded on the fly, ONE MFMA product, fp32 accumulation; y, res_pre, res_post
+ * (N,Cout<=32,2Di,2Hi,2Wi) 2-byte.  wx = dca_conv3d_lp_prep_weight(w (Cin,Cout,3,3,3), wx, Cin, Cout, src_ab 1, flip 0, dtype). */
+int dca_deconv3d_lp_forward(const float* x, const void* wx, void* y, const float* scale, const float* shift,
+                            const void* res_pre, const void* res_post, float slope, int N, int Cin, int Cout, int Di,
+                            int Hi, int Wi, int dtype, hipStream_t stream);
 /* nn.AvgPool3d((3,3,3), 2, 1) (cva.py:39): x (NC,Di,Hi,Wi) 2-byte -> y (NC,ceil/2...) fp32; Wi % 4 == 0.
  * F.interpolate(scale_factor=(2,2,2), mode='trilinear') (cva.py:64): x (NC,Di,Hi,Wi) fp32 -> y (NC,2Di,2Hi,2Wi) 2-byte. */
 int dca_avgpool3d_lp_fwd(const void* x, float* y, long NC, int Di, int Hi, int Wi, int dtype, hipStream_t stream);

@@ -101,6 +101,47 @@ def test_conv1x1_lp(case, lp):
     assert (err <= lim).all(), f"max err {err.max().item():.3e}"
 
 
+DC_CASES = [  # N, Cin, Cout, coarse dims, affine, slope, pre, post
+    (1, 64, 32, (2, 8, 16), True, 0.0, True, False),       # exactly one tile, cost_agg.conv3 form
+    (2, 64, 32, (3, 5, 12), True, 0.0, True, True),        # partial tiles, both residuals (cva1: + cost0)
+    (1, 16, 27, (2, 3, 5), False, 1.0, False, False),      # unaligned W, partial channel block, one chunk
+    (1, 48, 32, (5, 17, 36), True, 0.1, False, True),      # several tiles per workgroup range, 3 chunks
+]
+
+
+@pytest.mark.parametrize("lp", LPS, ids=["bf16", "fp16"])
+@pytest.mark.parametrize("exact", [False, True], ids=["lp", "fp32mfma"])
+@pytest.mark.parametrize("case", DC_CASES, ids=[str(c[:4]) for c in DC_CASES])
+def test_deconv3d_lp(case, lp, exact):
+    from dcanet_amd import ops
+    N, Cin, Cout, dims, aff, slope, pre, post = case
+    if exact and dims[2] % 4:
+        pytest.skip("the mixed-storage fp32-MFMA form needs W % 4 == 0")
+    odims = tuple(2 * d for d in dims)
+    x = seeded_tensor(f"dc.x{case}", (N, Cin) + dims)
+    w = seeded_tensor(f"dc.w{case}", (Cin, Cout, 3, 3, 3)) * (2.0 / (27 * Cin / 8)) ** 0.5
+    scale = (torch.rand(Cout) + 0.5) if aff else None
+    shift = torch.randn(Cout) * 0.1 if aff else None
+    rp = seeded_tensor(f"dc.p{case}", (N, Cout) + odims).to(lp) if pre else None
+    rq = seeded_tensor(f"dc.q{case}", (N, Cout) + odims).to(lp) if post else None
+    xr, wr = (x.double(), w.double()) if exact else (x.to(lp).double(), w.to(lp).double())
+    ref = F.conv_transpose3d(xr, wr, None, stride=2, padding=1, output_padding=1)
+    if aff:
+        ref = ref * scale.double().view(1, -1, 1, 1, 1) + shift.double().view(1, -1, 1, 1, 1)
+    if pre:
+        ref = ref + rp.double()
+    ref = torch.where(ref > 0, ref, ref * slope)
+    if post:
+        ref = ref + rq.double()
+    g = lambda t: None if t is None else t.to(DEV)
+    with torch.no_grad():
+        got = ops.deconv3d_lp(g(x), g(w), lp, g(scale), g(shift), slope, g(rp), g(rq), exact=exact)
+    assert got.dtype == lp and got.shape == ref.shape
+    err = (got.double().cpu() - ref).abs()
+    lim = 2e-5 * max(1.0, ref.abs().max().item()) + ulp(lp) * ref.abs()
+    assert (err <= lim).all(), f"max err {err.max().item():.3e}"
+
+
 def test_conv3d_lp_refuses_training():
     from dcanet_amd import ops
     x = torch.zeros(1, 32, 4, 8, 16, device=DEV, dtype=torch.bfloat16)

@@ -50,3 +50,13 @@ with torch.no_grad(), ops.frozen_weights():
     print(f"conv1 fp32 32->32                {ms*1e3:8.1f} us   {401.2/ms/1e3:6.2f} TB/s algorithmic")
     ms = timeit(lambda: ops.conv3d_fused_inference(x32, w2, 1, False, sc, sh, 1.0, x2=x32))
     print(f"conv1 fp32 64->32 (2 in)         {ms*1e3:8.1f} us   {601.8/ms/1e3:6.2f} TB/s algorithmic")
+
+with torch.no_grad(), ops.frozen_weights():
+    xc = torch.randn(1, 64, d // 2, h // 2, w // 2, device=dev)
+    wd = torch.randn(64, 32, 3, 3, 3, device=dev) * 0.05
+    for lp in (torch.bfloat16, torch.float16):
+        rp_ = torch.randn(1, 32, d, h, w, device=dev).to(lp)
+        for exact in (True, False):
+            ms = timeit(lambda: ops.deconv3d_lp(xc, wd, lp, sc, sh, 0.0, rp_, None, exact=exact))
+            print(f"deconv 64->32 {str(lp)[6:]:9s} {'fp32 MFMA, 2-byte out' if exact else 'lp kernel            '} {ms*1e3:8.1f} us   "
+                  f"{(50.1 + 200.6) / ms / 1e3:6.2f} TB/s algorithmic")
