@@ -55,6 +55,9 @@ SIGNATURES = {
     "dca_conv1_lp_prep_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "dca_conv1_lp_forward": (_i, [_p] * 8 + [_f, _i, _i, _i, _i, _l, _i, _i, _p]),
     "dca_conv3d_forward_mixed": (_i, [_p] * 7 + [_f] + [_i] * 12 + [_p]),
+    "dca_conv3d_s2_lp_weight_bytes": (_l, [_i]),
+    "dca_conv3d_s2_lp_prep_weight": (_i, [_p, _p, _i, _i, _i, _p]),
+    "dca_conv3d_s2_lp_forward": (_i, [_p] * 5 + [_f] + [_i] * 7 + [_p]),
     "dca_deconv3d_lp_forward": (_i, [_p] * 7 + [_f] + [_i] * 7 + [_p]),
     "dca_avgpool3d_lp_fwd": (_i, [_p, _p, _l, _i, _i, _i, _i, _p]),
     "dca_trilinear_up2_lp_fwd": (_i, [_p, _p, _l, _i, _i, _i, _i, _p]),

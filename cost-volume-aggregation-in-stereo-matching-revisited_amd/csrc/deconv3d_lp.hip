@@ -260,42 +260,40 @@ __global__ __launch_bounds__(512) void deconv3_lp_kernel(DlArgs a) {
     const __amdgpu_buffer_rsrc_t yr = dca_rsrc((char*)a.y + (long)n * osample * 2, osample * 2);
     const __amdgpu_buffer_rsrc_t pr = dca_rsrc((const char*)(has_pre ? a.res_pre : a.y) + (long)n * osample * 2, osample * 2);
     const __amdgpu_buffer_rsrc_t qr = dca_rsrc((const char*)(has_post ? a.res_post : a.y) + (long)n * osample * 2, osample * 2);
-    float sc[16], sh[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int cl = (r & 3) + 8 * (r >> 2) + 4 * half;
-      sc[r] = aff_lds[cl];
-      sh[r] = aff_lds[32 + cl];
-    }
 #pragma unroll
     for (int pd = 0; pd < 2; ++pd)
 #pragma unroll
       for (int ph = 0; ph < 2; ++ph) {
         // channel >= Cout is beyond the descriptor's range: dropped / read as zero by the hardware
         const int base = dca_pred_off((((2 * md + pd) * Ho + 2 * mh + ph) * Wo + 2 * mw + 4 * half * ostride) * 2, ok);
-        float rp0[16], rp1[16], rq0[16], rq1[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) rp0[r] = rp1[r] = rq0[r] = rq1[r] = 0.f;
-        if (has_pre) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const unsigned w_ = __builtin_amdgcn_raw_buffer_load_b32(pr, base + ((r & 3) + 8 * (r >> 2)) * ostride * 2, 0, 0);
-            rp0[r] = dl_lo<MT>(w_); rp1[r] = dl_hi<MT>(w_);
-          }
-        }
-        if (has_post) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const unsigned w_ = __builtin_amdgcn_raw_buffer_load_b32(qr, base + ((r & 3) + 8 * (r >> 2)) * ostride * 2, 0, 0);
-            rq0[r] = dl_lo<MT>(w_); rq1[r] = dl_hi<MT>(w_);
-          }
-        }
         const int pc0 = (pd * 2 + ph) * 2;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v0 = act_apply(acc[pc0][r] * sc[r] + sh[r] + rp0[r], a.slope) + rq0[r];
-          const float v1 = act_apply(acc[pc0 + 1][r] * sc[r] + sh[r] + rp1[r], a.slope) + rq1[r];
-          __builtin_amdgcn_raw_buffer_store_b32(dl_pack2<MT>(v0, v1), yr, base + ((r & 3) + 8 * (r >> 2)) * ostride * 2, 0, 0);
+        for (int rc = 0; rc < 16; rc += 8) {   // eight registers at a time: the 128 accumulators leave little room
+          unsigned wp[8], wq[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) wp[q] = wq[q] = 0u;
+          if (has_pre) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const int r = rc + q;
+              wp[q] = __builtin_amdgcn_raw_buffer_load_b32(pr, base + ((r & 3) + 8 * (r >> 2)) * ostride * 2, 0, 0);
+            }
+          }
+          if (has_post) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const int r = rc + q;
+              wq[q] = __builtin_amdgcn_raw_buffer_load_b32(qr, base + ((r & 3) + 8 * (r >> 2)) * ostride * 2, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int r = rc + q, cl = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float sc = aff_lds[cl], sh = aff_lds[32 + cl];
+            const float v0 = act_apply(acc[pc0][r] * sc + sh + dl_lo<MT>(wp[q]), a.slope) + dl_lo<MT>(wq[q]);
+            const float v1 = act_apply(acc[pc0 + 1][r] * sc + sh + dl_hi<MT>(wp[q]), a.slope) + dl_hi<MT>(wq[q]);
+            __builtin_amdgcn_raw_buffer_store_b32(dl_pack2<MT>(v0, v1), yr, base + ((r & 3) + 8 * (r >> 2)) * ostride * 2, 0, 0);
+          }
         }
       }
     if (tile + t_step < t_end) decode(tile + t_step, n, d0, h0, w0);

@@ -1132,19 +1132,33 @@ def trilinear_up2_lp(x, lp):
     return y
 
 
-def conv3d_s2_lp(x, weight, scale, shift, slope):
-    """3x3x3 stride-2 conv + folded BN + activation reading a 2-byte x, fp32 result (exact-fp32 MFMA arithmetic)."""
+def conv3d_s2_lp(x, weight, scale, shift, slope, exact=False):
+    """3x3x3 stride-2 conv + folded BN + activation reading a 2-byte x, fp32 result.  Default: weights rounded to x's
+    type, one MFMA product (csrc/conv3d_s2_lp.hip); exact=True keeps the fp32 MFMA arithmetic (csrc/conv3d_mfma.hip)."""
     x = _req_lp(x, "conv3d_s2_lp", x.dtype)
     weight = _req(weight, "conv3d_s2_lp.weight")
     N, Cin, D, H, W = x.shape
     Cout = weight.shape[0]
     Do, Ho, Wo = (D + 1) // 2, (H + 1) // 2, (W + 1) // 2
+    lib = _L()
+    code = _lp_code(x)
     with torch.cuda.device_of(x):
-        wt, Apad = _prep_weight(weight, Cin, Cout, 27, 0, 0, 3, 2, False)
         y = torch.empty((N, Cout, Do, Ho, Wo), device=x.device, dtype=torch.float32)
-        _chk(_L().dca_conv3d_forward_mixed(_ptr(x), _ptr(wt), _ptr(y), _ptr(scale), _ptr(shift), None, None, float(slope),
-                                           N, Cin, Cout, Apad, D, H, W, Do, Ho, Wo, 0, _lp_code(x), _stream()),
-             "dca_conv3d_forward_mixed")
+        if exact:
+            wt, Apad = _prep_weight(weight, Cin, Cout, 27, 0, 0, 3, 2, False)
+            _chk(lib.dca_conv3d_forward_mixed(_ptr(x), _ptr(wt), _ptr(y), _ptr(scale), _ptr(shift), None, None,
+                                              float(slope), N, Cin, Cout, Apad, D, H, W, Do, Ho, Wo, 0, code, _stream()),
+                 "dca_conv3d_forward_mixed")
+            return y
+
+        def build():
+            wx = torch.empty((lib.dca_conv3d_s2_lp_weight_bytes(Cin) // 2,), device=x.device, dtype=torch.int16)
+            _chk(lib.dca_conv3d_s2_lp_prep_weight(_ptr(weight), _ptr(wx), Cin, Cout, code, _stream()),
+                 "dca_conv3d_s2_lp_prep_weight")
+            return wx
+        wx = _memo(("lps2", Cin, Cout, code), (weight,), build)
+        _chk(lib.dca_conv3d_s2_lp_forward(_ptr(x), _ptr(wx), _ptr(y), _ptr(_opt(scale, "scale")), _ptr(_opt(shift, "shift")),
+                                          float(slope), N, Cin, Cout, D, H, W, code, _stream()), "dca_conv3d_s2_lp_forward")
     return y
 
 

@@ -255,6 +255,13 @@ int dca_conv3d_forward_mixed(const void* x, const float* wt, void* y, const floa
                              const void* res_pre, const void* res_post, float slope, int N, int Cin, int Cout, int CinPad,
                              int Di, int Hi, int Wi, int Do, int Ho, int Wo, int transposed, int dtype,
                              hipStream_t stream);
+/* Reduced-precision 3x3x3 stride-2 convolution (conv3d_s2_lp.hip; cost_agg.conv1 = convbn_3d(32, 64, 3, 2, 1) + ReLU,
+ * cva.py:16-17): x (N,Cin,D,H,W) 2-byte, ONE MFMA product, fp32 accumulation -> y (N,Cout<=64,ceil(D/2),..) fp32 =
+ * act(conv * scale + shift).  w: (Cout,Cin,3,3,3) fp32 -> wx (dca_conv3d_s2_lp_weight_bytes(Cin) bytes).  W % 4 == 0. */
+long dca_conv3d_s2_lp_weight_bytes(int Cin);
+int dca_conv3d_s2_lp_prep_weight(const float* w, void* wx, int Cin, int Cout, int dtype, hipStream_t stream);
+int dca_conv3d_s2_lp_forward(const void* x, const void* wx, float* y, const float* scale, const float* shift, float slope,
+                             int N, int Cin, int Cout, int D, int H, int W, int dtype, hipStream_t stream);
 /* Reduced-precision ConvTranspose3d(3, s2, p1, op1) (deconv3d_lp.hip; cost_agg.conv3 + ReLU(. + redir) [+ outer residual],
  * cva.py:21-29): x (N,Cin<=64,Di,Hi,Wi) fp32 rounded on the fly, ONE MFMA product, fp32 accumulation; y, res_pre, res_post
  * (N,Cout<=32,2Di,2Hi,2Wi) 2-byte.  wx = dca_conv3d_lp_prep_weight(w (Cin,Cout,3,3,3), wx, Cin, Cout, src_ab 1, flip 0, dtype). */

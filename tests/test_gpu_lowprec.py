@@ -142,6 +142,36 @@ def test_deconv3d_lp(case, lp, exact):
     assert (err <= lim).all(), f"max err {err.max().item():.3e}"
 
 
+S2_CASES = [  # N, Cin, Cout, fine dims, affine, slope
+    (1, 32, 64, (4, 16, 32), True, 0.0),       # exactly one tile, cost_agg.conv1 form
+    (2, 32, 64, (6, 10, 24), True, 0.0),       # partial tiles
+    (1, 40, 27, (5, 9, 20), False, 1.0),       # odd D / H (ceil), partial channel blocks, 5 chunks
+    (1, 8, 64, (10, 36, 72), True, 0.1),       # several tiles per workgroup range, one chunk
+]
+
+
+@pytest.mark.parametrize("lp", LPS, ids=["bf16", "fp16"])
+@pytest.mark.parametrize("exact", [False, True], ids=["lp", "fp32mfma"])
+@pytest.mark.parametrize("case", S2_CASES, ids=[str(c[:4]) for c in S2_CASES])
+def test_conv3d_s2_lp(case, lp, exact):
+    from dcanet_amd import ops
+    N, Cin, Cout, dims, aff, slope = case
+    x = seeded_tensor(f"s2.x{case}", (N, Cin) + dims).to(lp)
+    w = seeded_tensor(f"s2.w{case}", (Cout, Cin, 3, 3, 3)) * (2.0 / (27 * Cin)) ** 0.5
+    scale = (torch.rand(Cout) + 0.5) if aff else None
+    shift = torch.randn(Cout) * 0.1 if aff else None
+    ref = F.conv3d(x.double(), (w if exact else w.to(lp)).double(), None, 2, 1)
+    if aff:
+        ref = ref * scale.double().view(1, -1, 1, 1, 1) + shift.double().view(1, -1, 1, 1, 1)
+    ref = torch.where(ref > 0, ref, ref * slope)
+    g = lambda t: None if t is None else t.to(DEV)
+    with torch.no_grad():
+        got = ops.conv3d_s2_lp(g(x), g(w), g(scale), g(shift), slope, exact=exact)
+    assert got.dtype == torch.float32 and got.shape == ref.shape
+    err = (got.double().cpu() - ref).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), f"max err {err:.3e}"
+
+
 def test_conv3d_lp_refuses_training():
     from dcanet_amd import ops
     x = torch.zeros(1, 32, 4, 8, 16, device=DEV, dtype=torch.bfloat16)

@@ -60,3 +60,13 @@ with torch.no_grad(), ops.frozen_weights():
             ms = timeit(lambda: ops.deconv3d_lp(xc, wd, lp, sc, sh, 0.0, rp_, None, exact=exact))
             print(f"deconv 64->32 {str(lp)[6:]:9s} {'fp32 MFMA, 2-byte out' if exact else 'lp kernel            '} {ms*1e3:8.1f} us   "
                   f"{(50.1 + 200.6) / ms / 1e3:6.2f} TB/s algorithmic")
+
+with torch.no_grad(), ops.frozen_weights():
+    ws2 = torch.randn(64, 32, 3, 3, 3, device=dev) * 0.05
+    sc64, sh64 = torch.rand(64, device=dev) + 0.5, torch.randn(64, device=dev) * 0.1
+    for lp in (torch.bfloat16, torch.float16):
+        xl = x32.to(lp)
+        for exact in (True, False):
+            ms = timeit(lambda: ops.conv3d_s2_lp(xl, ws2, sc64, sh64, 0.0, exact=exact))
+            print(f"conv s2 32->64 {str(lp)[6:]:9s} {'fp32 MFMA, 2-byte in ' if exact else 'lp kernel            '} {ms*1e3:8.1f} us   "
+                  f"{(100.3 + 50.1) / ms / 1e3:6.2f} TB/s algorithmic")
