@@ -26,6 +26,13 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// Non-temporal output stores: y is written once, so it should not displace the halo lines the neighbouring tiles re-read
+// from this XCD's L2 -- 591 -> 568 us on the fused-epilogue 32->32 launch at 48x136x240 (tools/nt_ablate.sh).  (The same
+// switch on the reduced-precision kernel's 4-byte pair stores is a loss, 118 -> 150 us: partial lines.)
+#ifndef X3_NT
+#define X3_NT 1
+#endif
+
 namespace {
 
 constexpr int TD = 4, TH = 8, TW = 16;
@@ -339,7 +346,11 @@ __global__ __launch_bounds__(512) void conv3_bf16x3_kernel(X3Args a) {
         if (has_pre) v += rp[r];
         v = act_apply(v, a.slope);
         if (has_post) v += rq[r];
+#if X3_NT
+        dca_bstore1_nt(yr, v, voff + cu * cstride * 4, ok & (int)(cblk * 32 + cu + 4 * half < a.Cout));
+#else
         dca_bstore1(yr, v, voff + cu * cstride * 4, ok & (int)(cblk * 32 + cu + 4 * half < a.Cout));
+#endif
       }
     }
     n = nn; d0 = nd0; h0 = nh0; w0 = nw0;

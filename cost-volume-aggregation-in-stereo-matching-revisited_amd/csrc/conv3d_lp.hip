@@ -36,6 +36,9 @@ typedef _Float16 lp_f16x8 __attribute__((ext_vector_type(8)));
 #ifndef LP_SGB
 #define LP_SGB 1
 #endif
+#ifndef LP_NT      // non-temporal output stores
+#define LP_NT 0
+#endif
 #ifndef LP_DEFER   // experiment: epilogue deferred into the next tile's first step (slower: the VALU work does not hide)
 #define LP_DEFER 0
 #endif
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(512) void conv3_lp_kernel(LpArgs a) {
           const unsigned P = lp_pack2<MT>(v0, v1), Q = lp_swap1(P);
           // even lane: [my v0 | partner's v0]; odd lane: [partner's v1 | my v1]
           const unsigned word = __builtin_amdgcn_perm(P, Q, sel);
-          __builtin_amdgcn_raw_buffer_store_b32(word, yr, base + ((r & 3) + 8 * (r >> 2)) * cstride * 2, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(word, yr, base + ((r & 3) + 8 * (r >> 2)) * cstride * 2, 0, LP_NT ? 2 : 0);
         }
       }
     }

@@ -75,6 +75,11 @@ __device__ __forceinline__ float dca_bload1(__amdgpu_buffer_rsrc_t r, int byte_o
 __device__ __forceinline__ void dca_bstore1(__amdgpu_buffer_rsrc_t r, float v, int byte_off, int ok) {
   __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, dca_pred_off(byte_off, ok), 0, 0);
 }
+// non-temporal variant (gfx950 cache-policy bit 1 = nt): for outputs that are written once and read much later, so that
+// they do not displace the halo / weight lines the kernel re-reads from L2
+__device__ __forceinline__ void dca_bstore1_nt(__amdgpu_buffer_rsrc_t r, float v, int byte_off, int ok) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, dca_pred_off(byte_off, ok), 0, 2);
+}
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float2 dca_bload2(__amdgpu_buffer_rsrc_t r, int byte_off, int ok) {
   const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, dca_pred_off(byte_off, ok), 0, 0);
