@@ -138,21 +138,23 @@ __global__ void ctx_bwd_preds_kernel(const float* __restrict__ preds, const int*
 }
 
 // ---------------------------------------------------------------------------------------------
-// disparity attention, forward.  grid (ceil(HW/32), heads, B); thread = (pixel lane 0..31, query group 0..7)
+// disparity attention, forward.  grid (ceil(HW/PW), heads, B); thread = (pixel lane 0..PW-1, query group 0..7);
+// a thread owns the queries qg + 8t, t < QPT = ceil(n/8) <= 8, i.e. n <= 64 disparity bins.  PW = 32 pixels per
+// workgroup; the backward kernel drops to PW = 16 for n > 32 so that its five staged tiles still fit the 160 KB of LDS.
 // ---------------------------------------------------------------------------------------------
-template <int QPT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+template <int QPT, int PW>
+__global__ __launch_bounds__(8 * PW) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                        const float* __restrict__ v, float* __restrict__ out, int C,
                                                        int n, long HW) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* ks = smem;               // [8][n][32]
-  float* vs = smem + 8 * n * 32;  // [8][n][32]
-  const int tid = threadIdx.x, pl = tid & 31, qg = tid >> 5;
+  float* vs = smem + 8 * n * PW;  // [8][n][PW]
+  const int tid = threadIdx.x, pl = tid & (PW - 1), qg = tid / PW;
   const int head = blockIdx.y, b = blockIdx.z;
-  const long pix0 = (long)blockIdx.x * 32, pix = pix0 + pl;
+  const long pix0 = (long)blockIdx.x * PW, pix = pix0 + pl;
   const long hb = ((long)b * C + head * 8) * n * HW;  // offset of (b, head*8, 0, 0)
-  for (int it = tid; it < 8 * n * 32; it += 256) {
-    const int p = it & 31, cj = it >> 5;  // cj = c*n + j
+  for (int it = tid; it < 8 * n * PW; it += 8 * PW) {
+    const int p = it & (PW - 1), cj = it / PW;  // cj = c*n + j
     const bool ok = pix0 + p < HW;
     ks[it] = ok ? k[hb + (long)cj * HW + pix0 + p] : 0.f;
     vs[it] = ok ? v[hb + (long)cj * HW + pix0 + p] : 0.f;
@@ -175,8 +177,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     float kj[8], vj[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      kj[c] = ks[(c * n + j) * 32 + pl];
-      vj[c] = vs[(c * n + j) * 32 + pl];
+      kj[c] = ks[(c * n + j) * PW + pl];
+      vj[c] = vs[(c * n + j) * PW + pl];
     }
 #pragma unroll
     for (int t = 0; t < QPT; ++t) {
@@ -207,25 +209,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 //  phase 2, thread = (pixel, keys j = qg + 8t):  dk_j = sum_i dS_ij q_i / sqrt(8), dv_j = sum_i p_ij dout_i in registers.
 // A thread's QPT queries (keys) share every k/v (q/dout) value it reads from LDS, which divides the LDS traffic by QPT
 // and gives QPT independent dependency chains (the workgroup's 107 KB of LDS allow only one wave per SIMD).
-template <int QPT>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+template <int QPT, int PW>
+__global__ __launch_bounds__(8 * PW) void attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                        const float* __restrict__ v, const float* __restrict__ dout,
                                                        float* __restrict__ dq, float* __restrict__ dk,
                                                        float* __restrict__ dv, int C, int n, long HW) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tile = 8 * n * 32;
+  const int tile = 8 * n * PW;
   float* ks = smem;              // [8][n][32]
   float* vs = smem + tile;
   float* qs = smem + 2 * tile;   // pre-scaled by 1/sqrt(8)
   float* gs = smem + 3 * tile;   // dout
   float* st = smem + 4 * tile;   // [3][n][32]: m, 1/l, D
-  const int tid = threadIdx.x, pl = tid & 31, qg = tid >> 5;
+  const int tid = threadIdx.x, pl = tid & (PW - 1), qg = tid / PW;
   const int head = blockIdx.y, b = blockIdx.z;
-  const long pix0 = (long)blockIdx.x * 32, pix = pix0 + pl;
+  const long pix0 = (long)blockIdx.x * PW, pix = pix0 + pl;
   const long hb = ((long)b * C + head * 8) * n * HW;
   const float scale = 0.35355339059327373f;
-  for (int it = tid; it < tile; it += 256) {
-    const int p = it & 31, cj = it >> 5;
+  for (int it = tid; it < tile; it += 8 * PW) {
+    const int p = it & (PW - 1), cj = it / PW;
     const bool ok = pix0 + p < HW;
     const long g = hb + (long)cj * HW + pix0 + p;
     ks[it] = ok ? k[g] : 0.f;
@@ -241,8 +243,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
       const int i = min(qg + 8 * t, n - 1);
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        qv[t][c] = qs[(c * n + i) * 32 + pl];
-        go[t][c] = gs[(c * n + i) * 32 + pl];
+        qv[t][c] = qs[(c * n + i) * PW + pl];
+        go[t][c] = gs[(c * n + i) * PW + pl];
         dqv[t][c] = 0.f;
       }
       m[t] = -INFINITY; l[t] = 0.f; dnum[t] = 0.f;
@@ -251,8 +253,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
       float kj[8], vj[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        kj[c] = ks[(c * n + j) * 32 + pl];
-        vj[c] = vs[(c * n + j) * 32 + pl];
+        kj[c] = ks[(c * n + j) * PW + pl];
+        vj[c] = vs[(c * n + j) * PW + pl];
       }
 #pragma unroll
       for (int t = 0; t < QPT; ++t) {
@@ -276,17 +278,17 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
       inv[t] = 1.f / l[t];
       Dsum[t] = dnum[t] * inv[t];
       if (i < n) {
-        st[(0 * n + i) * 32 + pl] = m[t];
-        st[(1 * n + i) * 32 + pl] = inv[t];
-        st[(2 * n + i) * 32 + pl] = Dsum[t];
+        st[(0 * n + i) * PW + pl] = m[t];
+        st[(1 * n + i) * PW + pl] = inv[t];
+        st[(2 * n + i) * PW + pl] = Dsum[t];
       }
     }
     for (int j = 0; j < n; ++j) {
       float kj[8], vj[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        kj[c] = ks[(c * n + j) * 32 + pl];
-        vj[c] = vs[(c * n + j) * 32 + pl];
+        kj[c] = ks[(c * n + j) * PW + pl];
+        vj[c] = vs[(c * n + j) * PW + pl];
       }
 #pragma unroll
       for (int t = 0; t < QPT; ++t) {
@@ -318,8 +320,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
       const int j = min(qg + 8 * t, n - 1);
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        kj[t][c] = ks[(c * n + j) * 32 + pl];
-        vj[t][c] = vs[(c * n + j) * 32 + pl];
+        kj[t][c] = ks[(c * n + j) * PW + pl];
+        vj[t][c] = vs[(c * n + j) * PW + pl];
         dkj[t][c] = 0.f;
         dvj[t][c] = 0.f;
       }
@@ -328,10 +330,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
       float qv[8], go[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        qv[c] = qs[(c * n + i) * 32 + pl];
-        go[c] = gs[(c * n + i) * 32 + pl];
+        qv[c] = qs[(c * n + i) * PW + pl];
+        go[c] = gs[(c * n + i) * PW + pl];
       }
-      const float mi = st[(0 * n + i) * 32 + pl], li = st[(1 * n + i) * 32 + pl], Di = st[(2 * n + i) * 32 + pl];
+      const float mi = st[(0 * n + i) * PW + pl], li = st[(1 * n + i) * PW + pl], Di = st[(2 * n + i) * PW + pl];
 #pragma unroll
       for (int t = 0; t < QPT; ++t) {
         float s = 0.f, dp = 0.f;
@@ -405,41 +407,60 @@ extern "C" int dca_context_inject_bwd(const float* dkey, const float* x, const f
 
 extern "C" int dca_disp_attention_fwd(const float* q, const float* k, const float* v, float* out, int B, int C, int n,
                                       long HW, hipStream_t stream) {
-  DCA_REQUIRE(q && k && v && out && B > 0 && C > 0 && C % 8 == 0 && n > 0 && n <= 32 && HW > 0);
+  DCA_REQUIRE(q && k && v && out && B > 0 && C > 0 && C % 8 == 0 && n > 0 && n <= 64 && HW > 0);
   DCA_REQUIRE(C / 8 <= 65535 && B <= 65535);
   const size_t lds = (size_t)2 * 8 * n * 32 * 4;
   const dim3 grid(cdiv(HW, 32), C / 8, B);
   const int qpt = (n + 7) / 8;
-#define LAUNCH(Q)                                                                                         \
-  hipLaunchKernelGGL(attn_fwd_kernel<Q>, grid, dim3(256), lds, stream, q, k, v, out, C, n, HW)
-  if (qpt == 1) LAUNCH(1);
-  else if (qpt == 2) LAUNCH(2);
-  else if (qpt == 3) LAUNCH(3);
-  else LAUNCH(4);
+#define LAUNCH(Q)                                                                                                      \
+  do {                                                                                                                 \
+    if (lds > 64 * 1024) {                                                                                             \
+      hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<Q, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         (int)lds);                                                                    \
+      if (e != hipSuccess) return (int)e;                                                                              \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((attn_fwd_kernel<Q, 32>), grid, dim3(256), lds, stream, q, k, v, out, C, n, HW);                \
+  } while (0)
+  switch (qpt) {
+    case 1: LAUNCH(1); break;
+    case 2: LAUNCH(2); break;
+    case 3: LAUNCH(3); break;
+    case 4: LAUNCH(4); break;
+    case 5: LAUNCH(5); break;
+    case 6: LAUNCH(6); break;
+    case 7: LAUNCH(7); break;
+    default: LAUNCH(8); break;
+  }
 #undef LAUNCH
   return dca_launch_status();
 }
 
 extern "C" int dca_disp_attention_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq,
                                       float* dk, float* dv, int B, int C, int n, long HW, hipStream_t stream) {
-  DCA_REQUIRE(q && k && v && dout && dq && dk && dv && B > 0 && C > 0 && C % 8 == 0 && n > 0 && n <= 32 && HW > 0);
+  DCA_REQUIRE(q && k && v && dout && dq && dk && dv && B > 0 && C > 0 && C % 8 == 0 && n > 0 && n <= 64 && HW > 0);
   DCA_REQUIRE(C / 8 <= 65535 && B <= 65535);
-  const size_t lds = (size_t)(4 * 8 + 3) * n * 32 * 4;
-  const dim3 grid(cdiv(HW, 32), C / 8, B);
   const int qpt = (n + 7) / 8;
-#define LAUNCH(Q)                                                                                                      \
+#define LAUNCH(Q, PWV)                                                                                                 \
   do {                                                                                                                 \
+    const size_t lds = (size_t)(4 * 8 + 3) * n * PWV * 4;                                                              \
+    const dim3 grid(cdiv(HW, PWV), C / 8, B);                                                                          \
     if (lds > 64 * 1024) {                                                                                             \
-      hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel<Q>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                         (int)lds);                                                                    \
+      hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel<Q, PWV>,                                         \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
       if (e != hipSuccess) return (int)e;                                                                              \
     }                                                                                                                  \
-    hipLaunchKernelGGL(attn_bwd_kernel<Q>, grid, dim3(256), lds, stream, q, k, v, dout, dq, dk, dv, C, n, HW);         \
+    hipLaunchKernelGGL((attn_bwd_kernel<Q, PWV>), grid, dim3(8 * PWV), lds, stream, q, k, v, dout, dq, dk, dv, C, n, HW); \
   } while (0)
-  if (qpt == 1) LAUNCH(1);
-  else if (qpt == 2) LAUNCH(2);
-  else if (qpt == 3) LAUNCH(3);
-  else LAUNCH(4);
+  switch (qpt) {
+    case 1: LAUNCH(1, 32); break;
+    case 2: LAUNCH(2, 32); break;
+    case 3: LAUNCH(3, 32); break;
+    case 4: LAUNCH(4, 32); break;
+    case 5: LAUNCH(5, 16); break;     // n > 32: 16 pixels per workgroup keep the five staged tiles inside 160 KB of LDS
+    case 6: LAUNCH(6, 16); break;
+    case 7: LAUNCH(7, 16); break;
+    default: LAUNCH(8, 16); break;
+  }
 #undef LAUNCH
   return dca_launch_status();
 }

@@ -929,6 +929,11 @@ def context_inject(x, preds):
 
 
 def disparity_attention(q, k, v):
+    """softmax(q k^T / sqrt(8)) v along the disparity axis of every pixel, heads of 8 channels
+    (SelfAttention_bn.py:70-94).  Limits of the kernels: channels % 8 == 0 and at most 64 disparity bins."""
+    if q.dim() != 5 or q.shape[1] % 8 or q.shape[2] > 64:
+        raise RuntimeError(f"disparity_attention: needs (B, C % 8 == 0, n <= 64, H, W) tensors, got {tuple(q.shape)} "
+                           "(n = maxdisp/8 with the down-sampling cva, maxdisp/4 without)")
     return _DispAttention.apply(q, k, v)
 
 

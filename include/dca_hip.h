@@ -195,7 +195,7 @@ int dca_context_inject_bwd(const float* dkey, const float* x, const float* preds
                            float* part, int B, int C, int n, long HW, hipStream_t stream);
 
 /* ---- per-pixel disparity attention core -- SelfAttentionBlock.forward, SelfAttention_bn.py:70-94 ------
- * q,k,v,out: (B,C,n,HW), heads of 8 channels, softmax(q k^T / sqrt(8)) v over the n bins (n <= 32). */
+ * q,k,v,out: (B,C,n,HW), heads of 8 channels, softmax(q k^T / sqrt(8)) v over the n bins (n <= 64). */
 int dca_disp_attention_fwd(const float* q, const float* k, const float* v, float* out, int B, int C, int n, long HW,
                            hipStream_t stream);
 int dca_disp_attention_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq, float* dk,

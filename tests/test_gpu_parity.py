@@ -484,7 +484,8 @@ def test_golden_context_inject(golden):
         close(gx, g["gx"], 2e-6); close(gp, g["gp"], 2e-5)
 
 
-@pytest.mark.parametrize("shape", [(2, 32, 4, 6, 10), (1, 32, 24, 5, 13), (1, 32, 9, 4, 40), (1, 16, 32, 3, 7)])
+@pytest.mark.parametrize("shape", [(2, 32, 4, 6, 10), (1, 32, 24, 5, 13), (1, 32, 9, 4, 40), (1, 16, 32, 3, 7),
+                                   (1, 32, 48, 4, 9), (1, 16, 64, 3, 5), (1, 8, 33, 2, 19)])   # n > 32: cva(downsample=False)
 def test_attention_core(shape):
     _, ops = _mods()
     q, k, v = (seeded_tensor(f"at.{n}", shape) for n in "qkv")
