@@ -70,10 +70,18 @@ class GraphedTrainStep:
     stream, every buffer from torch's allocator.
 
     Construct it under the stream the training loop runs on; `__call__()` replays one step and returns the (static)
-    value `local_step` returned."""
+    value `local_step` returned.
 
-    def __init__(self, local_step, optimizer_step, all_reduce=None, warmup: int = 3):
+    Capture needs `warmup` REAL steps first (optimizer state, allocator pools, kernel attributes must exist before the
+    capture): they update parameters, optimizer moments and BatchNorm running statistics on the static batch.  Pass
+    `restore=` (an iterable of tensors: parameters, buffers, optimizer state) to have their values snapshotted before and
+    put back after the warm-up, so that the first replay is step 1 of the run; optimizer state that does not exist yet
+    (Adam's moments are created by the first step) is zeroed instead via `restore_optimizer=`."""
+
+    def __init__(self, local_step, optimizer_step, all_reduce=None, warmup: int = 3, restore=None,
+                 restore_optimizer=None):
         self.all_reduce = all_reduce
+        saved = [(t, t.detach().clone()) for t in (restore or [])]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                    # optimizer state, allocator pools, kernel attributes
@@ -84,6 +92,14 @@ class GraphedTrainStep:
                 optimizer_step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        with torch.no_grad():
+            for t, v in saved:
+                t.copy_(v)
+            if restore_optimizer is not None:
+                for st in restore_optimizer.state.values():
+                    for v in st.values():
+                        if torch.is_tensor(v):
+                            v.zero_()
         self.graph_a = torch.cuda.CUDAGraph()
         self.graph_b = None
         with torch.cuda.graph(self.graph_a):

@@ -53,7 +53,13 @@ class FlatGradBucket:
             p.grad = None
 
     def gather(self):
-        """copies the freshly assigned .grad tensors into the flat buffer (parameters without a gradient -> 0)"""
+        """copies the freshly assigned .grad tensors into the flat buffer (parameters without a gradient -> 0).
+
+        Note: a parameter that received no gradient this step gets a ZERO slice and `.grad` pointing at it (every rank
+        must hand the collective the same buffer layout).  An optimizer therefore still updates it through its moments /
+        weight decay, where the reference's `zero_grad()` + `step()` skips parameters whose `.grad` is None.  In DCANet's
+        training step every parameter of the hot path receives a gradient, so the two coincide; pass only the parameters
+        a step really trains if that matters."""
         src, dst = [], []
         for p, v in zip(self.params, self.views):
             if p.grad is None:

@@ -772,6 +772,19 @@ def test_graphed_train_step_matches_eager():
     torch.cuda.synchronize()
     worst = max(((a - b).abs().max() / (b.abs().max() + 1e-12)).item() for a, b in zip(pg, pe))
     assert worst == 0.0, worst                   # same kernels, same order, no atomics: bitwise
+    # restore=: the warm-up steps leave no trace -- two replays == two eager steps from the initial state
+    m_e2, m_g2 = copy.deepcopy(base), copy.deepcopy(base)
+    pe2, local_e2, opt_e2 = build(m_e2)
+    for _ in range(2):
+        local_e2(); opt_e2.step()
+    pg2, local_g2, opt_g2 = build(m_g2)
+    keep = list(m_g2.parameters()) + list(m_g2.buffers())
+    step2 = GraphedTrainStep(local_g2, opt_g2.step, restore=keep, restore_optimizer=opt_g2)
+    step2(); step2()
+    torch.cuda.synchronize()
+    worst2 = max(((a - b).abs().max() / (b.abs().max() + 1e-12)).item() for a, b in zip(pg2, pe2))
+    assert worst2 <= 1e-6, worst2
+    assert int(m_g2.dres0[0][1].num_batches_tracked) == int(m_e2.dres0[0][1].num_batches_tracked) == 2
 
 
 def test_prepack_plan_matches_per_call_packing():
