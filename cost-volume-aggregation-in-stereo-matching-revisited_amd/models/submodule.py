@@ -180,16 +180,8 @@ class Guidance(nn.Module):
 
 class PropgationNet_4x(nn.Module):
     """reference models/submodule.py:357-373 (identical copy models/gwcnet_dca_g.py:108-124):
-    9-neighbour convex x4 up-sampling of the 1/4-res disparity, values scaled by 4.
-
-    Same children / state-dict keys as the reference (`conv.0.0` Conv2d 64->128, `conv.0.1` BatchNorm2d, `conv.2` Conv2d
-    128->144), but none of their forwards is called: the two 3x3 mask convolutions run on this package's 3D convolution
-    kernels with the batch as the depth axis -- a (B,C,H,W) map is the (1,C,B,H,W) volume and the 2D weight the centre
-    depth-plane of a 3x3x3 weight whose other planes are zero, so samples never mix, BatchNorm2d's statistics over
-    (B,H,W) are BatchNorm3d's over (1,B,H,W), and forward, backward-data and weight gradient are the fp32-grade bf16x3
-    kernels (MIOpen's fp32 Winograd kernels spent 7.4 ms per stereo pair and training step on these two layers, more
-    than the whole BatchNorm traffic of the 3D path).  Everything after the convolutions is one fused kernel
-    (csrc/heads2d.hip: unfold . softmax over the 9 neighbours . sum . pixel shuffle)."""
+    9-neighbour convex x4 up-sampling of the 1/4-res disparity, values scaled by 4.  The mask conv stays on
+    PyTorch-ROCm (2D); everything after it is one fused kernel."""
 
     def __init__(self, base_channels):
         super().__init__()
@@ -198,34 +190,6 @@ class PropgationNet_4x(nn.Module):
                                   nn.Conv2d(base_channels * 2, 9 * 16, kernel_size=(3, 3), stride=(1, 1), padding=1,
                                             dilation=(1, 1), bias=False))
 
-    @staticmethod
-    def _w3(conv2d):
-        """(Cout,Cin,3,3) -> (Cout,Cin,3,3,3) with the 2D kernel in the centre depth plane (differentiable; inside
-        ops.frozen_weights() built once per weight so that the packed images behind it are reused as well)"""
-        w = conv2d.weight
-        if torch.is_grad_enabled() and w.requires_grad:
-            return F.pad(w.unsqueeze(2), (0, 0, 0, 0, 1, 1))
-        return ops._memo(("w2dto3d",), (w,), lambda: F.pad(w.detach().unsqueeze(2), (0, 0, 0, 0, 1, 1)))
-
-    def mask_logits(self, guidance):
-        B = guidance.shape[0]
-        x = guidance.unsqueeze(2) if B == 1 else guidance.transpose(0, 1).unsqueeze(0)     # (1 | B -> depth)
-        conv1, bn1, conv2 = self.conv[0][0], self.conv[0][1], self.conv[2]
-        if not bn1.training and not torch.is_grad_enabled():
-            C = bn1.num_features
-            with torch.cuda.device_of(guidance):
-                stats = ops.bn_eval_affine(bn1)
-            lp = ops._lp_dtype()
-            if lp is not None:
-                h = ops.conv3d_lp(x, self._w3(conv1), lp, stats[2 * C:3 * C], stats[3 * C:], 0.0, out_dtype=lp)
-                y = ops.conv3d_lp(h, self._w3(conv2), lp, out_dtype=torch.float32)
-            else:
-                h = ops.conv3d_fused_inference(x, self._w3(conv1), 1, False, stats[2 * C:3 * C], stats[3 * C:], 0.0)
-                y = ops.conv3d(h, self._w3(conv2), 1, False)
-        else:
-            h = ops.bn_act(ops.conv3d(x, self._w3(conv1), 1, False), bn1, 0.0)
-            y = ops.conv3d(h, self._w3(conv2), 1, False)
-        return y.squeeze(2) if B == 1 else y.squeeze(0).transpose(0, 1)
-
     def forward(self, guidance, disp):
-        return ops.convex_upsample4(self.mask_logits(guidance), disp)
+        # unfold(4*disp) . softmax_9(mask) . sum . pixel-shuffle as one HIP kernel (csrc/heads2d.hip)
+        return ops.convex_upsample4(self.conv(guidance), disp)
