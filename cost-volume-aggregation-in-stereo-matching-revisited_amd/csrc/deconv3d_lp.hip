@@ -98,7 +98,9 @@ __global__ __launch_bounds__(512) void deconv3_lp_kernel(DlArgs a) {
     aff_lds[tid] = has_aff ? (tid < 32 ? a.scale[co] : a.shift[co]) : (tid < 32 ? 1.f : 0.f);
   }
   // this lane's coarse position inside the tile, and the byte offset of its voxel in a halo image
-  const int rr = wv * 2 + (l31 >> 4), dl = rr >> 3, hl = rr & 7, wl = l31 & 15;
+  // (second h-row of the column tile rotated by -1 voxel: its row starts IW*16 = 272 B = 16 B (mod 256) after the first,
+  // and ds_read_b128's non-contiguous 16-lane groups would otherwise see 2-way bank conflicts -- see conv3d_lp.hip)
+  const int rr = wv * 2 + (l31 >> 4), dl = rr >> 3, hl = rr & 7, wl = (l31 & 16) ? (((l31 & 15) - 1) & 15) : (l31 & 15);
   const int boff = (half * NVOX + (dl * IH + hl) * IW + wl) * 16;
 
   const int cstride = a.Di * a.Hi * a.Wi;

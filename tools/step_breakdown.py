@@ -8,7 +8,7 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "gwc_fwd" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "gwc_fwd" in r["Kernel_Name"] or "gwc_fused" in r["Kernel_Name"]]
 # last pair of gwc_fwd launches with a whole step between them (kernel_roofline() launches gwc_fwd back to back at the end)
 pairs = [(a, b) for a, b in zip(idx[:-1], idx[1:]) if b - a > 100]
 a, b = pairs[-2] if len(pairs) > 1 else pairs[-1]   # the last pair also spans the micro-benchmarks after the timed loop
