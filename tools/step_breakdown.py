@@ -11,7 +11,10 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "gwc_fwd" in r["Kernel_Name"] or "gwc_fused" in r["Kernel_Name"]]
 # last pair of gwc_fwd launches with a whole step between them (kernel_roofline() launches gwc_fwd back to back at the end)
 pairs = [(a, b) for a, b in zip(idx[:-1], idx[1:]) if b - a > 100]
-a, b = pairs[-2] if len(pairs) > 1 else pairs[-1]   # the last pair also spans the micro-benchmarks after the timed loop
+# the window with the MEDIAN launch count: the first ones contain warm-up work (weight packing, MIOpen searches), the last
+# one also spans the micro-benchmarks after the timed loop
+pairs.sort(key=lambda p: p[1] - p[0])
+a, b = pairs[len(pairs) // 2]
 win = rows[a:b]
 tot, cnt = collections.Counter(), collections.Counter()
 for r in win:
