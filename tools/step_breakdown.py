@@ -11,10 +11,10 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "gwc_fwd" in r["Kernel_Name"] or "gwc_fused" in r["Kernel_Name"]]
 # last pair of gwc_fwd launches with a whole step between them (kernel_roofline() launches gwc_fwd back to back at the end)
 pairs = [(a, b) for a, b in zip(idx[:-1], idx[1:]) if b - a > 100]
-# the window with the MEDIAN launch count: the first ones contain warm-up work (weight packing, MIOpen searches), the last
+# the last window with the MOST COMMON launch count: the first ones contain warm-up work (weight packing, MIOpen searches), the last
 # one also spans the micro-benchmarks after the timed loop
-pairs.sort(key=lambda p: p[1] - p[0])
-a, b = pairs[len(pairs) // 2]
+mode = collections.Counter(p[1] - p[0] for p in pairs).most_common(1)[0][0]
+a, b = [p for p in pairs if p[1] - p[0] == mode][-1]
 win = rows[a:b]
 tot, cnt = collections.Counter(), collections.Counter()
 for r in win:
