@@ -10,7 +10,7 @@ top = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "gwc_fwd" in r["Kernel_Name"] or "gwc_fused" in r["Kernel_Name"]]
 # last pair of gwc_fwd launches with a whole step between them (kernel_roofline() launches gwc_fwd back to back at the end)
-pairs = [(a, b) for a, b in zip(idx[:-1], idx[1:]) if b - a > 100]
+pairs = [(a, b) for a, b in zip(idx[:-1], idx[1:]) if b - a > 40]
 # the last window with the MOST COMMON launch count: the first ones contain warm-up work (weight packing, MIOpen searches), the last
 # one also spans the micro-benchmarks after the timed loop
 mode = collections.Counter(p[1] - p[0] for p in pairs).most_common(1)[0][0]
