@@ -61,8 +61,13 @@ template <typename MT> __device__ __forceinline__ float c1_hi(unsigned w) {
 constexpr int MAXCH = 8;   // 16-channel chunks over both inputs (Cin <= 128)
 
 // S % 4 == 0 and 8-byte aligned bases (the caller checks); OUT32: fp32 output and residuals
+// two workgroups per CU (<= 256 registers per lane): 59.6 -> 41.9 us (32->32) and 66.5 -> 53.4 us (64->32, two inputs) at
+// 48x136x240 -- 4.8 / 5.6 TB/s; three or four per CU make hipcc spill (82 / 161 us)
+#ifndef C1_OCC
+#define C1_OCC 2
+#endif
 template <typename MT, bool OUT32>
-__global__ __launch_bounds__(256) void conv1_lp_kernel(C1LpArgs a) {
+__global__ __launch_bounds__(256, C1_OCC) void conv1_lp_kernel(C1LpArgs a) {
   typedef typename C1<MT>::vec8 vec8;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
   const int nch = a.NCH1 + a.NCH2;

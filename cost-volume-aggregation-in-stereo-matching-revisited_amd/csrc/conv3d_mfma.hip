@@ -475,23 +475,29 @@ __global__ __launch_bounds__(256, 2) void deconv3_mfma_kernel(ConvArgs a) {
 // [v0+4i..]; MFMA tile j is the voxel set {v0+4i+j}, so loads and stores are 16 B per lane.
 // The weight fragments stay in registers.
 // ---------------------------------------------------------------------------------------------
+// Round 2: the channels of a group go in two batches of 8 k-pairs, scale / shift live in LDS and the epilogue handles two
+// output rows at a time (124 -> 120 us for 32->32 at 48x136x240).  Forcing two workgroups per CU (CONV1_OCC=2) still
+// spills (131 us): a wave's 64 fp32 MFMAs (4096 matrix-pipe cycles per 128 voxels) are the latency this kernel cannot
+// hide, which is what the reduced-precision conv1_lp.hip (1536 cycles, 4.8-5.6 TB/s) does not have.
+#ifndef CONV1_OCC
+#define CONV1_OCC 1
+#endif
 template <int NG, bool VEC>
-__global__ __launch_bounds__(256) void conv1_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, CONV1_OCC) void conv1_mfma_kernel(ConvArgs a) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
   const long DHW = (long)a.Do * a.Ho * a.Wo;
   const long ngroups = (DHW + 127) / 128, total = (long)a.N * ngroups;
+  __shared__ float aff[64];
+  const bool has_aff = a.scale != nullptr, has_pre = a.res_pre != nullptr, has_post = a.res_post != nullptr;
+  if (threadIdx.x < 64) {
+    const int co = min((int)(threadIdx.x & 31), a.Cout - 1);
+    aff[threadIdx.x] = has_aff ? (threadIdx.x < 32 ? a.scale[a.co_off + co] : a.shift[a.co_off + co])
+                               : (threadIdx.x < 32 ? 1.f : 0.f);
+  }
   float aw[NG * 16];
 #pragma unroll
   for (int kk = 0; kk < NG * 16; ++kk) aw[kk] = a.wt[(2 * kk + half) * 32 + l31];
-
-  const bool has_aff = a.scale != nullptr, has_pre = a.res_pre != nullptr, has_post = a.res_post != nullptr;
-  float sc[16], sh[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int co = min((r & 3) + 8 * (r >> 2) + 4 * half, a.Cout - 1);
-    sc[r] = has_aff ? a.scale[a.co_off + co] : 1.f;
-    sh[r] = has_aff ? a.shift[a.co_off + co] : 0.f;
-  }
+  __syncthreads();
   // hardware-predicated loads of the activations (dca_common.h): 32-bit offsets inside one (sample, tensor)
   const bool boff_ok = a.xs_n * 4 < 0x7ffffff0L && a.x2s_n * 4 < 0x7ffffff0L;
   for (long g = (long)blockIdx.x * 4 + wv; g < total; g += (long)gridDim.x * 4) {
@@ -505,56 +511,60 @@ __global__ __launch_bounds__(256) void conv1_mfma_kernel(ConvArgs a) {
 #pragma unroll
     for (int grp = 0; grp < NG; ++grp) {
       const float* xbase = (grp == 0 ? a.x + n * a.xs_n : a.x2 + n * a.x2s_n);
-      float4 b[16];
-      if (VEC && boff_ok) {
-        const __amdgpu_buffer_rsrc_t xr = dca_rsrc(xbase, (grp == 0 ? a.xs_n : a.x2s_n) * 4);
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk)
-          b[kk] = dca_bload4(xr, (int)(((long)(2 * kk + half) * DHW + v) * 4), (int)(v < DHW));
-      } else {
+      for (int hb = 0; hb < 2; ++hb) {       // two batches of 8 k-pairs (16 channels)
+        float4 b[8];
+        if (VEC && boff_ok) {
+          const __amdgpu_buffer_rsrc_t xr = dca_rsrc(xbase, (grp == 0 ? a.xs_n : a.x2s_n) * 4);
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-          const float* p = xbase + v + (long)(2 * kk + half) * DHW;
-          b[kk].x = (v + 0 < DHW) ? p[0] : 0.f;
-          b[kk].y = (v + 1 < DHW) ? p[1] : 0.f;
-          b[kk].z = (v + 2 < DHW) ? p[2] : 0.f;
-          b[kk].w = (v + 3 < DHW) ? p[3] : 0.f;
+          for (int kk = 0; kk < 8; ++kk)
+            b[kk] = dca_bload4(xr, (int)(((long)(2 * (hb * 8 + kk) + half) * DHW + v) * 4), (int)(v < DHW));
+        } else {
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) {
+            const float* p = xbase + v + (long)(2 * (hb * 8 + kk) + half) * DHW;
+            b[kk].x = (v + 0 < DHW) ? p[0] : 0.f;
+            b[kk].y = (v + 1 < DHW) ? p[1] : 0.f;
+            b[kk].z = (v + 2 < DHW) ? p[2] : 0.f;
+            b[kk].w = (v + 3 < DHW) ? p[3] : 0.f;
+          }
         }
-      }
 #pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
-        const float w = aw[grp * 16 + kk];
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b[kk].x, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b[kk].y, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b[kk].z, acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b[kk].w, acc[3], 0, 0, 0);
+        for (int kk = 0; kk < 8; ++kk) {
+          const float w = aw[grp * 16 + hb * 8 + kk];
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b[kk].x, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b[kk].y, acc[1], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b[kk].z, acc[2], 0, 0, 0);
+          acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b[kk].w, acc[3], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the next batch's 8 loads behind this batch's MFMAs (register budget)
       }
     }
     const bool inr = v < DHW;
     const long base = ((long)n * a.CoutTotal + a.co_off) * DHW + (inr ? v : 0);
     if (VEC) {
 #pragma unroll
-      for (int rc = 0; rc < 16; rc += 4) {  // 4 rows at a time: enough loads in flight, no spills
-        float4 rp[4], rq[4];
+      for (int rc = 0; rc < 16; rc += 2) {  // two rows at a time
+        float4 rp[2], rq[2];
         if (has_pre) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
+          for (int q = 0; q < 2; ++q) {
             const int r = rc + q;
             rp[q] = *(const float4*)(a.res_pre + base + min((r & 3) + 8 * (r >> 2) + 4 * half, a.Cout - 1) * DHW);
           }
         }
         if (has_post) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
+          for (int q = 0; q < 2; ++q) {
             const int r = rc + q;
             rq[q] = *(const float4*)(a.res_post + base + min((r & 3) + 8 * (r >> 2) + 4 * half, a.Cout - 1) * DHW);
           }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int r = rc + q, co = (r & 3) + 8 * (r >> 2) + 4 * half;
-          float o[4] = {acc[0][r] * sc[r] + sh[r], acc[1][r] * sc[r] + sh[r], acc[2][r] * sc[r] + sh[r],
-                        acc[3][r] * sc[r] + sh[r]};
+        for (int q = 0; q < 2; ++q) {
+          const int r = rc + q, cl = (r & 3) + 8 * (r >> 2) + 4 * half, co = cl;
+          const float sc = aff[cl], sh = aff[32 + cl];
+          float o[4] = {acc[0][r] * sc + sh, acc[1][r] * sc + sh, acc[2][r] * sc + sh, acc[3][r] * sc + sh};
           if (has_pre) { o[0] += rp[q].x; o[1] += rp[q].y; o[2] += rp[q].z; o[3] += rp[q].w; }
 #pragma unroll
           for (int j = 0; j < 4; ++j) o[j] = act_apply(o[j], a.slope);
