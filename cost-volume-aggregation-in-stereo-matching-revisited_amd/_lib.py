@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(HERE, "libdca_hip.so")
 
 _p, _i, _l, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double
 
-ABI_VERSION = 4   # == DCA_ABI_VERSION of include/dca_hip.h
+ABI_VERSION = 5   # == DCA_ABI_VERSION of include/dca_hip.h
 
 # name -> (restype, argtypes); mirrors include/dca_hip.h one to one
 SIGNATURES = {
@@ -24,6 +24,9 @@ SIGNATURES = {
     "dca_up_softargmin_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "dca_conv3d_prep_weight": (_i, [_p, _p] + [_i] * 9 + [_p]),
     "dca_conv3d_forward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _f] + [_i] * 16 + [_p]),
+    "dca_conv1_x3_weight_bytes": (_l, [_i]),
+    "dca_conv1_x3_prep_weight": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "dca_conv1_x3_forward": (_i, [_p] * 8 + [_f] + [_i] * 6 + [_l, _p]),
     "dca_conv3d_prep_many": (_i, [_p, _i, _p]),
     "dca_conv3d_x3_weight_bytes": (_l, [_i, _i]),
     "dca_conv3d_x3_prep_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),

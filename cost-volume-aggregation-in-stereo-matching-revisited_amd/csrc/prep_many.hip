@@ -9,7 +9,8 @@ namespace {
 struct PrepDesc {          // mirrored by ops.PrepackPlan (72 bytes)
   const float* src;
   void* dst;
-  int kind;                // 0: fp32 image (dca_conv3d_prep_weight), 1: bf16x3 image (dca_conv3d_x3_prep_weight)
+  int kind;                // 0: fp32 image (dca_conv3d_prep_weight), 1: bf16x3 image (dca_conv3d_x3_prep_weight),
+                           // 2: bf16x3 fragments of a 1x1x1 conv (dca_conv1_x3_prep_weight)
   int A, Bn, Apad, Bpad, K, src_ab, flip, Btotal, b_off, NCH, pad_;
   long total;              // elements of dst
 };
@@ -35,6 +36,16 @@ __global__ __launch_bounds__(256) void prep_many_kernel(const PrepDesc* __restri
                      : d.src[((long)(d.b_off + bi) * d.A + ai) * d.K + st];
       }
       ((float*)d.dst)[idx] = v;
+    } else if (d.kind == 2) {
+      const int j = idx & 7, lane = (idx >> 3) & 63, term = (int)((idx >> 9) % 3), chunk = (int)((idx >> 9) / 3);
+      const int bi = lane & 31, ai = chunk * 16 + 8 * (lane >> 5) + j;
+      float v = 0.f;
+      if (ai < d.A && bi < d.Bn)
+        v = d.src_ab ? d.src[(long)ai * d.Btotal + d.b_off + bi] : d.src[(long)(d.b_off + bi) * d.A + ai];
+      __bf16 h, m, l;
+      split3(v, h, m, l);
+      const __bf16 o = term == 0 ? h : (term == 1 ? m : l);
+      ((unsigned short*)d.dst)[idx] = __builtin_bit_cast(unsigned short, o);
     } else {
       const int j = idx & 7, lane = (idx >> 3) & 63;
       long t = idx >> 9;
@@ -60,7 +71,8 @@ __global__ __launch_bounds__(256) void prep_many_kernel(const PrepDesc* __restri
 
 // table: n device-resident 72-byte descriptors {src, dst, kind, A, Bn, Apad, Bpad, K, src_ab, flip, Btotal, b_off, NCH,
 // pad, total} (pointers 8 bytes, ints 4, total 8) with the argument meaning of dca_conv3d_prep_weight (kind 0) /
-// dca_conv3d_x3_prep_weight (kind 1: A, Bn, src_ab, flip, NCH = ceil(A/16), total = weight_bytes/2).
+// dca_conv3d_x3_prep_weight (kind 1: A, Bn, src_ab, flip, NCH = ceil(A/16), total = weight_bytes/2) /
+// dca_conv1_x3_prep_weight (kind 2: A, Bn, src_ab, Btotal, b_off, total = weight_bytes/2).
 extern "C" int dca_conv3d_prep_many(const void* table, int n, hipStream_t stream) {
   DCA_REQUIRE(table && n > 0 && n <= 65535 && (((uintptr_t)table) & 7) == 0);
   hipLaunchKernelGGL(prep_many_kernel, dim3(48, n), dim3(256), 0, stream, (const PrepDesc*)table);

@@ -298,6 +298,19 @@ def _x3_eligible(x, x2, ksize, stride, transposed, A, B):
     return tiles >= _X3_MIN_WORKGROUPS and max(A, B) * D * H * W * 4 < 0x7ffffff0
 
 
+def _c1x3_eligible(x, x2, ksize, A, C1, y):
+    """1x1x1 convs on the bf16x3 kernel of conv1_x3.hip (fp32-grade, LDS-free): channel layouts it is built for, voxel
+    count divisible by 4, 16-byte aligned tensors"""
+    if not CONV_X3 or ksize != 1:
+        return False
+    C2 = 0 if x2 is None else x2.shape[1]
+    if (C1, C2) not in ((32, 0), (64, 0), (32, 32)) or A != C1 + C2:
+        return False
+    S = x[0, 0].numel()
+    ptrs = [x.data_ptr(), y.data_ptr()] + ([] if x2 is None else [x2.data_ptr()])
+    return S % 4 == 0 and all(p % 16 == 0 for p in ptrs) and 64 * S * 4 < 0x7ffffff0
+
+
 def _slice_width(ksize, stride, transposed, B):
     """output channels one launch of dca_conv3d_forward produces (include/dca_hip.h)"""
     if ksize == 1 or transposed:
@@ -353,6 +366,23 @@ def _conv_sliced(x, x2, w_src, A, B, K, src_ab, flip, ksize, stride, transposed,
         _chk(lib.dca_conv3d_x3_forward(_ptr(x), _ptr(wx), _ptr(y), _ptr(scale), _ptr(shift), _ptr(res_pre),
                                        _ptr(res_post), float(slope), N, A, B, Di, Hi, Wi, _stream()),
              "dca_conv3d_x3_forward")
+        return y
+    if _c1x3_eligible(x, x2, ksize, A, C1, y):
+        S = Do * Ho * Wo
+        C2 = 0 if x2 is None else x2.shape[1]
+        for b0 in range(0, B, 32):
+            bn = min(32, B - b0)
+
+            def build_c1(b0=b0, bn=bn):
+                wf = torch.empty((lib.dca_conv1_x3_weight_bytes(A) // 2,), device=x.device, dtype=torch.int16)
+                _chk(lib.dca_conv1_x3_prep_weight(_ptr(w_src), _ptr(wf), A, bn, int(src_ab), B, b0, _stream()),
+                     "dca_conv1_x3_prep_weight")
+                return wf
+            wf = _memo(("c1x3prep", A, B, int(src_ab), b0, bn), (w_src,), build_c1,
+                       (2, A, bn, 0, 0, 1, int(src_ab), 0, B, b0))
+            _chk(lib.dca_conv1_x3_forward(_ptr(x), _ptr(x2), _ptr(wf), _ptr(y), _ptr(scale), _ptr(shift), _ptr(res_pre),
+                                          _ptr(res_post), float(slope), N, C1, C2, bn, B, b0, S, _stream()),
+                 "dca_conv1_x3_forward")
         return y
     for b0 in range(0, B, width):
         bn = min(width, B - b0)

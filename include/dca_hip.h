@@ -23,7 +23,7 @@ extern "C" {
 
 /* Bumped whenever an argument list below changes; the ctypes loader (_lib.py) refuses a library built from another
  * version of this header. */
-#define DCA_ABI_VERSION 4
+#define DCA_ABI_VERSION 5
 int dca_abi_version(void);
 
 /* storage types of the reduced-precision inference path (0 = fp32) */
@@ -110,6 +110,17 @@ int dca_conv3d_forward(const float* x, const float* x2, const float* wt, float* 
 long dca_conv3d_wgrad_workspace(int N, int Cx, int Cy, int Do, int Ho, int Wo, int ksize, int stride);
 int dca_conv3d_wgrad(const float* x, const float* dy, float* part, float* dw, int N, int Cx, int Cy, int Di, int Hi,
                      int Wi, int Do, int Ho, int Wo, int ksize, int stride, long s_cy, long s_cx, hipStream_t stream);
+
+/* 1x1x1 convolutions with fp32 tensors on the bf16 matrix pipe, fp32-grade (conv1_x3.hip: the exact three-way split of
+ * conv3d_bf16x3.hip on an LDS-free data path): same contract as dca_conv3d_forward(ksize 1) -- x (N,C1,S) [, x2 (N,C2,S)],
+ * y (N,CoutTotal,S) channels [co_off, co_off+Cout), Cout <= 32, (C1,C2) in {(32,0),(64,0),(32,32)}, S % 4 == 0.
+ * wfrag (dca_conv1_x3_weight_bytes(A) bytes) from w read as W[b][a] = src_ab ? w[a*Btotal + b_off + b] : w[(b_off+b)*A + a]. */
+long dca_conv1_x3_weight_bytes(int A);
+int dca_conv1_x3_prep_weight(const float* w, void* wfrag, int A, int Bn, int src_ab, int Btotal, int b_off,
+                             hipStream_t stream);
+int dca_conv1_x3_forward(const float* x, const float* x2, const void* wfrag, float* y, const float* scale,
+                         const float* shift, const float* res_pre, const float* res_post, float slope, int N, int C1,
+                         int C2, int Cout, int CoutTotal, int co_off, long S, hipStream_t stream);
 
 /* Batched weight re-layout: ONE launch for n descriptors of dca_conv3d_prep_weight (kind 0) / dca_conv3d_x3_prep_weight
  * (kind 1) work (prep_many.hip) -- a training step re-packs every conv weight after the optimizer update, and ~130
