@@ -298,6 +298,15 @@ def _x3_eligible(x, x2, ksize, stride, transposed, A, B):
     return tiles >= _X3_MIN_WORKGROUPS and max(A, B) * D * H * W * 4 < 0x7ffffff0
 
 
+def _dx3_eligible(x, x2, ksize, stride, transposed, A, B):
+    """transposed 3x3x3 stride-2 convs on the bf16x3 kernel of deconv3d_x3.hip: <= 32 output channels, coarse width
+    divisible by 4, 16-byte aligned input"""
+    if not CONV_X3 or not transposed or ksize != 3 or stride != 2 or x2 is not None or B > 32 or A > 64:
+        return False
+    N, _, D, H, W = x.shape
+    return W % 4 == 0 and x.data_ptr() % 16 == 0 and max(A, 8) * D * H * W * 4 < 0x7ffffff0 and 256 * D * H * W * 4 < 0x7ffffff0
+
+
 def _c1x3_eligible(x, x2, ksize, A, C1, y):
     """1x1x1 convs on the bf16x3 kernel of conv1_x3.hip (fp32-grade, LDS-free): channel layouts it is built for, voxel
     count divisible by 4, 16-byte aligned tensors"""
@@ -366,6 +375,18 @@ def _conv_sliced(x, x2, w_src, A, B, K, src_ab, flip, ksize, stride, transposed,
         _chk(lib.dca_conv3d_x3_forward(_ptr(x), _ptr(wx), _ptr(y), _ptr(scale), _ptr(shift), _ptr(res_pre),
                                        _ptr(res_post), float(slope), N, A, B, Di, Hi, Wi, _stream()),
              "dca_conv3d_x3_forward")
+        return y
+    if _dx3_eligible(x, x2, ksize, stride, transposed, A, B):
+        def build_dx3():
+            w3 = torch.empty((lib.dca_conv3d_x3_weight_bytes(A, B) // 2,), device=x.device, dtype=torch.int16)
+            _chk(lib.dca_conv3d_x3_prep_weight(_ptr(w_src), _ptr(w3), A, B, int(src_ab), int(flip), _stream()),
+                 "dca_conv3d_x3_prep_weight")
+            return w3
+        wx = _memo(("x3prep", A, B, int(src_ab), int(flip)), (w_src,), build_dx3,
+                   (1, A, B, 0, 0, 27, int(src_ab), int(flip), B, 0))
+        _chk(lib.dca_deconv3d_x3_forward(_ptr(x), _ptr(wx), _ptr(y), _ptr(scale), _ptr(shift), _ptr(res_pre),
+                                         _ptr(res_post), float(slope), N, A, B, Di, Hi, Wi, _stream()),
+             "dca_deconv3d_x3_forward")
         return y
     if _c1x3_eligible(x, x2, ksize, A, C1, y):
         S = Do * Ho * Wo

@@ -23,7 +23,7 @@ extern "C" {
 
 /* Bumped whenever an argument list below changes; the ctypes loader (_lib.py) refuses a library built from another
  * version of this header. */
-#define DCA_ABI_VERSION 5
+#define DCA_ABI_VERSION 6
 int dca_abi_version(void);
 
 /* storage types of the reduced-precision inference path (0 = fp32) */
@@ -144,6 +144,16 @@ int dca_conv3d_x3_prep_weight(const float* w, void* wx, int A, int B, int src_ab
 int dca_conv3d_x3_forward(const float* x, const void* wx, float* y, const float* scale, const float* shift,
                           const float* res_pre, const float* res_post, float slope, int N, int Cin, int Cout, int D,
                           int H, int W, hipStream_t stream);
+
+/* ConvTranspose3d(k 3, stride 2, padding 1, output_padding 1) with fp32 tensors on the bf16 matrix pipe, same exact
+ * three-way split (deconv3d_x3.hip): `cost_agg.conv3` forward (models/augment/cva.py:21-29) and the backward-data of
+ * `cost_agg.conv1` (cva.py:16-17).  x (N,Cin,Di,Hi,Wi) -> y (N,Cout<=32,2Di,2Hi,2Wi) = act(deconv * scale + shift +
+ * res_pre) + res_post, the epilogue contract of dca_conv3d_forward.  wx = dca_conv3d_x3_prep_weight(w, wx, A = Cin,
+ * B = Cout, src_ab, flip 0) (w[a][b][27] for src_ab 1).  Requires Wi % 4 == 0, 16-byte aligned x / wx, 8-byte aligned y and
+ * residuals (hipErrorInvalidValue otherwise: callers use dca_conv3d_forward(transposed 1)). */
+int dca_deconv3d_x3_forward(const float* x, const void* wx, float* y, const float* scale, const float* shift,
+                            const float* res_pre, const float* res_post, float slope, int N, int Cin, int Cout, int Di,
+                            int Hi, int Wi, hipStream_t stream);
 
 /* Weight gradient of the 3x3x3 / stride-1 / pad-1 convolution on the bf16 matrix pipe with the same exact three-way
  * bf16 split (conv3d_wgrad_bf16x3.hip); replaces dca_conv3d_wgrad for ksize 3, stride 1 (autograd's dW of the nn.Conv3d

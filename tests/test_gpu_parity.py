@@ -144,12 +144,14 @@ CONV_CASES = [
 @pytest.mark.parametrize("x3", [False, True], ids=["fp32mfma", "bf16x3"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[str(c[:5]) + str(c[5]) for c in CONV_CASES])
 def test_conv3d(case, x3, monkeypatch):
-    """x3 = False: the fp32 MFMA kernels everywhere; True: 3x3x3 stride-1 forward / backward-data on the bf16x3 split
-    kernel (the shipped default), everything else unchanged"""
+    """x3 = False: the fp32 MFMA kernels everywhere; True: 3x3x3 stride-1 forward / backward-data and the transposed
+    convolution (= backward-data of the stride-2 one) on the bf16x3 split kernels (the shipped default), everything else
+    unchanged"""
     _, ops = _mods()
     monkeypatch.setattr(ops, "CONV_X3", x3)
-    if x3 and not (case[2] == 3 and case[3] == 1 and not case[4] and case[1] > 1):
-        pytest.skip("the bf16x3 kernel serves 3x3x3 stride-1 convolutions only")
+    if x3 and not (case[2] == 3 and case[1] > 1):
+        pytest.skip("bf16x3 kernels: 3x3x3 stride-1 convolutions, transposed convolutions (<= 32 output channels) and the "
+                    "backward-data of the stride-2 ones; the 1x1x1 kernel has its own test")
     cin, cout, k, stride, transposed, dims, N = case
     x = seeded_tensor(f"cv.x{case}", (N, cin) + dims)
     wshape = (cin, cout, k, k, k) if transposed else (cout, cin, k, k, k)
@@ -199,6 +201,58 @@ def test_conv3d_bf16x3_path(case, monkeypatch):
     y = ops.conv3d(xg, wg, 1, False)
     gx, gw = torch.autograd.grad((y * gy.to(DEV)).sum(), [xg, wg])
     close(y, yr, 1e-5, "fwd"); close(gx, gxr, 1e-5, "dx"); close_l2(gw, gwr, 1e-5, "dw")
+
+
+DX3_CASES = [
+    # cin, cout, coarse dims, N  (W % 4 == 0: the kernel's only staging path; 1 - 4 channel chunks, partial chunk / block)
+    (64, 32, (2, 3, 4), 2),
+    (64, 32, (4, 5, 36), 1),
+    (64, 32, (5, 9, 20), 2),
+    (32, 32, (3, 4, 8), 1),
+    (40, 27, (3, 8, 16), 1),
+    (16, 32, (2, 9, 12), 3),
+    (64, 32, (7, 17, 32), 1),
+]
+
+
+@pytest.mark.parametrize("case", DX3_CASES, ids=[str(c) for c in DX3_CASES])
+def test_deconv3d_bf16x3(case, monkeypatch):
+    """deconv3d_x3.hip against fp64: ConvTranspose3d(3, s2, p1, op1) forward with and without the fused epilogue, and the
+    same kernel as backward-data of the stride-2 convolution (models/augment/cva.py:16-29)"""
+    _, ops = _mods()
+    monkeypatch.setattr(ops, "CONV_X3", True)
+    cin, cout, dims, N = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn((N, cin) + dims, generator=g)
+    w = torch.randn(cin, cout, 3, 3, 3, generator=g) * (1.0 / (cin * 27 / 8) ** 0.5)
+    xg, wg = x.to(DEV), w.to(DEV)
+    assert ops._dx3_eligible(xg, None, 3, 2, True, cin, cout)
+    ref = F.conv_transpose3d(x.double(), w.double(), None, 2, 1, 1)
+    y = ops.conv3d(xg, wg, 2, True)
+    tol = 2e-6 * ref.abs().max().item()
+    assert (y.cpu().double() - ref).abs().max().item() <= tol
+    # must be at least as accurate as the fp32 MFMA kernel
+    monkeypatch.setattr(ops, "CONV_X3", False)
+    e32 = (ops.conv3d(xg, wg, 2, True).cpu().double() - ref).abs().max().item()
+    monkeypatch.setattr(ops, "CONV_X3", True)
+    assert (y.cpu().double() - ref).abs().max().item() <= 2.0 * max(e32, 1e-7 * ref.abs().max().item())
+    # fused epilogue: relu(y * scale + shift + res_pre) + res_post
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    rp, rq = torch.randn(ref.shape, generator=g), torch.randn(ref.shape, generator=g)
+    yf = ops.conv3d_fused_inference(xg, wg, 2, True, sc.to(DEV), sh.to(DEV), 0.0, rp.to(DEV), rq.to(DEV))
+    rf = torch.relu(ref * sc.double().view(1, -1, 1, 1, 1) + sh.double().view(1, -1, 1, 1, 1) + rp.double()) + rq.double()
+    assert (yf.cpu().double() - rf).abs().max().item() <= 2e-6 * rf.abs().max().item() + tol
+    # backward-data of Conv3d(cout_c = cin, cin_c = cout, 3, stride 2): dy coarse (N, cin) -> dx fine (N, cout)
+    wc = torch.randn(cin, cout, 3, 3, 3, generator=g) * 0.1            # Conv3d weight (out = cin, in = cout)
+    xf = torch.randn((N, cout) + tuple(2 * d for d in dims), generator=g)
+    xfd, wcd = xf.double().requires_grad_(), wc.double()
+    yc = F.conv3d(xfd, wcd, None, 2, 1)
+    gy = torch.randn(yc.shape, generator=g)
+    (gxr,) = torch.autograd.grad((yc * gy.double()).sum(), [xfd])
+    xfg = xf.to(DEV).requires_grad_()
+    yg = ops.conv3d(xfg, wc.to(DEV), 2, False)
+    (gx,) = torch.autograd.grad((yg * gy.to(DEV)).sum(), [xfg])
+    assert (gx.cpu().double() - gxr).abs().max().item() <= 2e-6 * gxr.abs().max().item()
 
 
 def test_conv3d_bf16x3_random_shapes(monkeypatch):

@@ -18,7 +18,7 @@ a, b = [p for p in pairs if p[1] - p[0] == mode][-1]
 win = rows[a:b]
 tot, cnt = collections.Counter(), collections.Counter()
 for r in win:
-    n = r["Kernel_Name"].split("(")[0][:64]
+    n = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][:64]
     tot[n] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); cnt[n] += 1
 wall = int(win[-1]["End_Timestamp"]) - int(win[0]["Start_Timestamp"])
 print("steps found %d; window wall %.2f ms, kernel sum %.2f ms, launches %d" % (len(idx), wall / 1e6, sum(tot.values()) / 1e6, len(win)))
