@@ -16,13 +16,22 @@
 // pass 1 = odd planes (taps kd = 0 and kd = 2), each followed by its own epilogue (whole output rows either way).
 // A "step" is one (16-channel chunk, kd) pair: 9 taps x 6 products = 54 MFMAs per wave on a 27 KB slab of pre-split
 // weight fragments (the layout of dca_conv3d_x3_prep_weight, so the forward conv's packed weights are reused) and the
-// chunk's coarse 3 x 9 x 17 halo, kept in LDS as FP32 (29 KB, [k half][channel quad][voxel][4 floats]: a lane's 8-channel
-// fragment is two conflict-free ds_read_b128) and split into the three bf16 terms IN REGISTERS when a fragment is used
-// (11 VALU instructions per channel pair, spread between the MFMAs of all eight waves; splitting at staging time
-// instead put ~250 VALU instructions per step on the four waves that own staging items and cost 25 % of the run time).
-// Both are double buffered in LDS: in the MIDDLE of step s the registers holding step s+1's data (requested in the
-// middle of step s-1, so a whole step of latency budget) are written to the idle buffers and step s+2's loads are
-// issued; one barrier per step.
+// chunk's coarse 3 x 9 x 17 halo, kept in LDS as FP32 (29 KB, [k half][channel quad][voxel][4 floats]: a lane's
+// 8-channel fragment is two conflict-free ds_read_b128); both double buffered.
+//
+// Schedule: the two waves that share a SIMD (wave w and w + 4) share its matrix pipe AND its vector issue, so running
+// all eight waves through "54 MFMAs, then stage" in lockstep leaves the matrix pipe idle while everybody stages
+// (measured: MFMA core 411 us + staging 180 us + epilogues 125 us = the whole 706 us at batch 4, 30 % MFMA busy).
+// Instead the workgroup runs as two half-groups in opposite phases (MI355X_MICROARCH.md, "Two waves per SIMD"): in
+// slot 2s waves 0-3 issue the MFMAs of step s while waves 4-7 are in their "load slot" -- write their half of step
+// s+1's data (fetched into registers one slot earlier) into the idle LDS buffers and request their half of step s+2
+// -- and in slot 2s+1 the roles swap; one barrier per slot.  In-kernel s_memtime stamps (DX3_STAMP, tools/dx3_stamps.py)
+// showed what a load slot can afford: beside the partner's MFMA stream a vector instruction of the loading wave takes
+// ~18 cycles, so splitting the halo into bf16 terms there (90 instructions) made the load slot (2500 cycles) longer
+// than the compute slot (2250); the computing wave's own vector instructions between its MFMAs are nearly free.  Hence
+// the split into the three bf16 terms happens IN REGISTERS in the compute slot, per neighbour fragment, interleaved
+// with the MFMAs (11 instructions per channel pair), the pass epilogue runs at the end of the compute slot, and a load
+// slot is nothing but waits, register moves and LDS stores.
 #include "dca_common.h"
 #include "../../include/dca_hip.h"
 
@@ -31,10 +40,19 @@ typedef __bf16 dx_bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef DX3_NT
 #define DX3_NT 1
 #endif
-// timing ablations (tools/dx3_ablate.sh; results are garbage): 1 no MFMAs, 2 no mid-step staging, 4 no epilogue,
-// 8 no per-tap weight-fragment LDS reads, 16 no halo-fragment LDS reads
-#ifndef DX3_ABL
-#define DX3_ABL 0
+#ifndef DX3_SOFF
+#define DX3_SOFF 1
+#endif
+
+// DX3_STAMP (debug build, tools/dx3_stamps.py): res_post is reinterpreted as an unsigned long long buffer that receives
+// s_memtime stamps of the first 96 slots of workgroup 0, waves 0 and 4
+#ifndef DX3_STAMP
+#define DX3_STAMP 0
+#endif
+#if DX3_STAMP
+#define DX3_MARK(i) do { if (stamp_on && k < 96) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) stamps[(grp * 96 + k) * 6 + (i)] = t_; } } while (0)
+#else
+#define DX3_MARK(i) do { } while (0)
 #endif
 
 namespace {
@@ -46,10 +64,12 @@ constexpr int B_PLANE = NVOX * 16;                  // 7344 B: voxel x 4 fp32 ch
 constexpr int B_IMG = 4 * B_PLANE;                  // 29376 B: planes (k half, channel quad) of a 16-channel chunk
 constexpr int A_SLAB = 9 * 3 * 1024;                // 9 taps x 3 terms x (64 lanes x 16 B)
 constexpr int LDS_BYTES = 2 * B_IMG + 2 * A_SLAB;   // 114048
-constexpr int NROWS = 2 * ID * IH;                  // 54 (k half, d, h) rows of IW = 17 voxels: 5 aligned quads
-constexpr int NQ = NROWS * 5;                       // 270 quad items (8 x b128 loads each): one per thread
-constexpr int KA = (A_SLAB / 16 + 511) / 512;       // 4 b128 per thread (1728 per slab)
-static_assert(NQ <= 512, "one quad item per thread");
+constexpr int NROWS = 2 * ID * IH;                  // 54 (k half, d, h) rows of IW = 17 voxels: 9 aligned pairs
+constexpr int NPAIR = NROWS * 9;                    // 486 pair items (8 x b64 loads each)
+constexpr int HALF_PAIR = NPAIR / 2;                // 243 per half-group: one per thread
+constexpr int HALF_A = A_SLAB / 16 / 2;             // 864 b128 of a slab per half-group
+constexpr int KA = (HALF_A + 255) / 256;            // 4 per thread
+static_assert(HALF_PAIR <= 256 && NPAIR % 2 == 0, "one pair item per thread");
 
 struct DxArgs {
   const float* x;
@@ -65,27 +85,36 @@ struct DxArgs {
   int nTD, nTH, nTW;
 };
 
-constexpr int q0(int t) { return t; }
 __device__ __forceinline__ unsigned dx_pack2(float a, float b) {   // v_cvt_pk_bf16_f32
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   typedef __bf16 bfx2 __attribute__((ext_vector_type(2)));
   const f32x2 v = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bfx2));
 }
-// exact three-way split of 8 fp32 values (channel pairs packed): f[0] + f[1] + f[2] == v to 24 bits
-__device__ __forceinline__ void dx_split8(const float4 lo, const float4 hi, dx_bf16x8 (&f)[3]) {
-  const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-  u32x4 H, M, L;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float va = v[2 * j], vb = v[2 * j + 1];
-    const unsigned h2 = dx_pack2(va, vb);
-    const float ra = va - __uint_as_float(h2 << 16), rb = vb - __uint_as_float(h2 & 0xffff0000u);      // exact
-    const unsigned m2 = dx_pack2(ra, rb);
-    const unsigned l2 = dx_pack2(ra - __uint_as_float(m2 << 16), rb - __uint_as_float(m2 & 0xffff0000u));
-    H[j] = h2; M[j] = m2; L[j] = l2;
-  }
-  f[0] = __builtin_bit_cast(dx_bf16x8, H); f[1] = __builtin_bit_cast(dx_bf16x8, M); f[2] = __builtin_bit_cast(dx_bf16x8, L);
+__device__ __forceinline__ float dx_sub(float a, float b) {   // plain v_sub_f32: hipcc's SLP pass would pair these into
+  float r;                                                     // v_pk_add_f32, which is slow beside MFMAs
+  asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// exact three-way split of channel pair j of a lane's 8 fp32 values (lo = channels 0..3, hi = 4..7) into dword j of the
+// three bf16 fragments: H + M + L == v to 24 bits
+__device__ __forceinline__ void dx_split_h(const float4 lo, const float4 hi, int j, u32x4& H) {
+  const float va = j == 0 ? lo.x : (j == 1 ? lo.z : (j == 2 ? hi.x : hi.z));
+  const float vb = j == 0 ? lo.y : (j == 1 ? lo.w : (j == 2 ? hi.y : hi.w));
+  H[j] = dx_pack2(va, vb);
+}
+__device__ __forceinline__ void dx_split_ml(const float4 lo, const float4 hi, int j, const u32x4& H, u32x4& M, u32x4& L) {
+  const float va = j == 0 ? lo.x : (j == 1 ? lo.z : (j == 2 ? hi.x : hi.z));
+  const float vb = j == 0 ? lo.y : (j == 1 ? lo.w : (j == 2 ? hi.y : hi.w));
+  const unsigned h2 = H[j];
+  const float ra = dx_sub(va, __uint_as_float(h2 << 16)), rb = dx_sub(vb, __uint_as_float(h2 & 0xffff0000u));      // exact
+  const unsigned m2 = dx_pack2(ra, rb);
+  M[j] = m2;
+  L[j] = dx_pack2(dx_sub(ra, __uint_as_float(m2 << 16)), dx_sub(rb, __uint_as_float(m2 & 0xffff0000u)));
+}
+__device__ __forceinline__ void dx_split_pair(const float4 lo, const float4 hi, int j, u32x4& H, u32x4& M, u32x4& L) {
+  dx_split_h(lo, hi, j, H);
+  dx_split_ml(lo, hi, j, H, M, L);
 }
 
 // Wi % 4 == 0 and a 16-byte aligned x (the caller checks)
@@ -95,13 +124,20 @@ __global__ __launch_bounds__(512) void deconv3_bf16x3_kernel(DxArgs a) {
   char* a_lds = smem + 2 * B_IMG;     // two weight slabs
   __shared__ float aff_lds[64];
 
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: the slot role and the cursors stay scalar
+  const int grp = wv >> 2, gt = tid & 255;
   const long T = (long)a.N * a.nTD * a.nTH * a.nTW;
   const int nx = gridDim.x >= 8 ? 8 : 1, xcd = blockIdx.x % nx;
   const int cnt = (gridDim.x - xcd + nx - 1) / nx;
   const int t_begin = (int)(T * xcd / nx) + blockIdx.x / nx, t_end = (int)(T * (xcd + 1) / nx), t_step = cnt;
   if (t_begin >= t_end) return;
 
+#if DX3_STAMP
+  unsigned long long* stamps = (unsigned long long*)a.res_post;
+  a.res_post = nullptr;
+  const bool stamp_on = blockIdx.x == 0 && (wv == 0 || wv == 4);
+#endif
   const bool has_aff = a.scale != nullptr, has_pre = a.res_pre != nullptr, has_post = a.res_post != nullptr;
   if (tid < 64) {
     const int co = min(tid & 31, a.Cout - 1);
@@ -116,6 +152,7 @@ __global__ __launch_bounds__(512) void deconv3_bf16x3_kernel(DxArgs a) {
   const int cstride = a.Di * a.Hi * a.Wi;
   const long sample = (long)a.Cin * cstride;
   const int S = 3 * a.NCH;                       // steps per tile
+  const bool cin_full = (a.Cin & 15) == 0, cout_full = a.Cout == 32;
   const __amdgpu_buffer_rsrc_t wr = dca_rsrc(a.wx, (long)a.NCH * 3 * A_SLAB);
 
   // step s of a tile: s < NCH: pass 0 (kd = 1), chunk s; else pass 1: chunk (s - NCH) / 2, kd = 0 then 2
@@ -123,58 +160,64 @@ __global__ __launch_bounds__(512) void deconv3_bf16x3_kernel(DxArgs a) {
   auto step_kd = [&](int s) __attribute__((always_inline)) { return s < a.NCH ? 1 : ((s - a.NCH) & 1) * 2; };
   auto step_newb = [&](int s) __attribute__((always_inline)) { return s < a.NCH || ((s - a.NCH) & 1) == 0; };
 
+  // ---- staging: each half-group moves half of a step's data, global -> registers -> (split) -> LDS
   float4 ra[KA];
+  int a_voff[KA];      // gt * 16, or out of range for the pieces beyond the half slab
+#pragma unroll
+  for (int k = 0; k < KA; ++k) a_voff[k] = dca_pred_off(gt * 16, (int)(gt + 256 * k < HALF_A));
   auto load_A = [&](int s) __attribute__((always_inline)) {
-    const int base = (step_chunk(s) * 3 + step_kd(s)) * A_SLAB;
+    // the slab / piece part of every address is a scalar offset: no vector instruction per load (a vector instruction of
+    // a loading wave costs ~18 cycles beside the partner's MFMAs)
+    const int sbase = (step_chunk(s) * 3 + step_kd(s)) * A_SLAB + grp * HALF_A * 16;
 #pragma unroll
     for (int k = 0; k < KA; ++k) {
-      const int it = tid + 512 * k;
-      ra[k] = dca_bload4(wr, base + it * 16, (int)(it < A_SLAB / 16));
+      const u32x4 v = DX3_SOFF ? __builtin_amdgcn_raw_buffer_load_b128(wr, a_voff[k], sbase + 256 * 16 * k, 0)
+                               : __builtin_amdgcn_raw_buffer_load_b128(wr, a_voff[k] + sbase + 256 * 16 * k, 0, 0);
+      ra[k] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     }
   };
   auto store_A = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < KA; ++k) {
-      const int it = tid + 512 * k;
-      if (it < A_SLAB / 16) *(float4*)(a_lds + buf * A_SLAB + it * 16) = ra[k];
+      const int it = gt + 256 * k;
+      if (it < HALF_A) *(float4*)(a_lds + buf * A_SLAB + (grp * HALF_A + it) * 16) = ra[k];
     }
   };
-
-  float4 rq[8];
-  int item_crd;   // id | ih << 8 | quad << 16 | k half << 24
+  u32x2 rq[8];
+  int item_crd;   // id | ih << 8 | pair << 16 | k half << 24
   {
-    const int row = tid / 5, q = tid - row * 5;
+    const int it = grp * HALF_PAIR + gt, row = it / 9, p = it - row * 9;
     const int kh = row / (ID * IH), rem = row - kh * (ID * IH), id = rem / IH, ih = rem - id * IH;
-    item_crd = (tid < NQ) ? (id | (ih << 8) | (q << 16) | (kh << 24)) : -1;
+    item_crd = (gt < HALF_PAIR) ? (id | (ih << 8) | (p << 16) | (kh << 24)) : -1;
   }
   auto load_B = [&](int n, int d0, int h0, int w0, int chunk) __attribute__((always_inline)) {
     // channel >= Cin lands beyond the descriptor's range -> zero (partial last chunk)
     const __amdgpu_buffer_rsrc_t xr = dca_rsrc(a.x + (long)n * sample, sample * 4);
     const int crd = item_crd;
-    const int di = d0 + (crd & 255), hi = h0 + ((crd >> 8) & 255), wi = w0 + 4 * ((crd >> 16) & 255);
+    const int di = d0 + (crd & 255), hi = h0 + ((crd >> 8) & 255), wi = w0 + 2 * ((crd >> 16) & 255);
     const int c0 = chunk * 16 + ((crd >> 24) & 1) * 8;
-    const int okv = (int)(crd >= 0) & (int)(di < a.Di) & (int)(hi < a.Hi) & (int)(wi < a.Wi);   // Wi % 4 == 0
+    const int okv = (int)(crd >= 0) & (int)(di < a.Di) & (int)(hi < a.Hi) & (int)(wi < a.Wi);   // Wi even: a pair is in or out
     const int base = dca_pred_off((c0 * cstride + (di * a.Hi + hi) * a.Wi + wi) * 4, okv);
+    // the channel part of the address as a scalar offset (no vector instruction per load) -- but scalar offsets are
+    // excluded from the hardware range check, which a partial last chunk relies on, so only when Cin fills its chunks
+    if (cin_full && DX3_SOFF) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xr, base + j * cstride * 4, 0, 0);
-      rq[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+      for (int j = 0; j < 8; ++j) rq[j] = __builtin_amdgcn_raw_buffer_load_b64(xr, base, j * cstride * 4, 0);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) rq[j] = __builtin_amdgcn_raw_buffer_load_b64(xr, base + j * cstride * 4, 0, 0);
     }
   };
   auto store_B = [&](int buf) __attribute__((always_inline)) {
     const int crd = item_crd;
     if (crd >= 0) {
-      const int q = (crd >> 16) & 255;
-      char* p0 = b_lds + buf * B_IMG + 2 * ((crd >> 24) & 1) * B_PLANE + (((crd & 255) * IH + ((crd >> 8) & 255)) * IW + 4 * q) * 16;
-      *(float4*)p0 = make_float4(rq[0].x, rq[1].x, rq[2].x, rq[3].x);
-      *(float4*)(p0 + B_PLANE) = make_float4(rq[4].x, rq[5].x, rq[6].x, rq[7].x);
-      if (q < 4) {   // the row has 17 voxels: the fifth quad contributes one
-        *(float4*)(p0 + 16) = make_float4(rq[0].y, rq[1].y, rq[2].y, rq[3].y);
-        *(float4*)(p0 + B_PLANE + 16) = make_float4(rq[4].y, rq[5].y, rq[6].y, rq[7].y);
-        *(float4*)(p0 + 32) = make_float4(rq[0].z, rq[1].z, rq[2].z, rq[3].z);
-        *(float4*)(p0 + B_PLANE + 32) = make_float4(rq[4].z, rq[5].z, rq[6].z, rq[7].z);
-        *(float4*)(p0 + 48) = make_float4(rq[0].w, rq[1].w, rq[2].w, rq[3].w);
-        *(float4*)(p0 + B_PLANE + 48) = make_float4(rq[4].w, rq[5].w, rq[6].w, rq[7].w);
+      const int p = (crd >> 16) & 255;
+      char* p0 = b_lds + buf * B_IMG + 2 * ((crd >> 24) & 1) * B_PLANE + (((crd & 255) * IH + ((crd >> 8) & 255)) * IW + 2 * p) * 16;
+      *(u32x4*)p0 = u32x4{rq[0].x, rq[1].x, rq[2].x, rq[3].x};
+      *(u32x4*)(p0 + B_PLANE) = u32x4{rq[4].x, rq[5].x, rq[6].x, rq[7].x};
+      if (p < 8) {   // the row has 17 voxels: the ninth pair contributes one
+        *(u32x4*)(p0 + 16) = u32x4{rq[0].y, rq[1].y, rq[2].y, rq[3].y};
+        *(u32x4*)(p0 + B_PLANE + 16) = u32x4{rq[4].y, rq[5].y, rq[6].y, rq[7].y};
       }
     }
   };
@@ -185,144 +228,216 @@ __global__ __launch_bounds__(512) void deconv3_bf16x3_kernel(DxArgs a) {
     n = tile / a.nTD;
     d0 = td * TD; h0 = th * TH; w0 = tw * TW;
   };
-  struct Cursor { int tile, s, n, d0, h0, w0; };
+  // a step and the LDS buffers it lives in (pa: weight slab buffer, toggles every step; pb: halo image, toggles when
+  // the step brings a new chunk)
+  struct Cursor { int tile, s, n, d0, h0, w0, pa, pb; };
   auto advance = [&](Cursor& c) __attribute__((always_inline)) {
-    if (c.s + 1 < S) { ++c.s; return; }
-    c.s = 0;
-    c.tile += t_step;
-    if (c.tile < t_end) decode(c.tile, c.n, c.d0, c.h0, c.w0);
+    c.pa ^= 1;
+    if (c.s + 1 < S) {
+      ++c.s;
+    } else {
+      c.s = 0;
+      c.tile += t_step;
+      if (c.tile < t_end) decode(c.tile, c.n, c.d0, c.h0, c.w0);
+    }
+    if (step_newb(c.s)) c.pb ^= 1;
   };
 
-  Cursor cur{t_begin, 0, 0, 0, 0, 0}, c1, c2;
+  const int Do = 2 * a.Di, Ho = 2 * a.Hi, Wo = 2 * a.Wi;
+  const int ostride = Do * Ho * Wo;
+  const long osample = (long)a.Cout * ostride;
+
+  Cursor cur{t_begin, 0, 0, 0, 0, 0, 0, 0}, st, ld;
   decode(t_begin, cur.n, cur.d0, cur.h0, cur.w0);
   load_B(cur.n, cur.d0, cur.h0, cur.w0, 0);
   load_A(0);
   store_B(0);
   store_A(0);
-  c1 = cur;
-  advance(c1);       // S >= 3: the second step always exists
-  load_A(c1.s);
-  if (step_newb(c1.s)) load_B(c1.n, c1.d0, c1.h0, c1.w0, step_chunk(c1.s));
-  c2 = c1;
-  advance(c2);
+  st = cur;
+  advance(st);       // S >= 3: the second step always exists
+  load_A(st.s);
+  if (step_newb(st.s)) load_B(st.n, st.d0, st.h0, st.w0, step_chunk(st.s));
+  ld = st;
+  advance(ld);
   __syncthreads();
 
-  const int Do = 2 * a.Di, Ho = 2 * a.Hi, Wo = 2 * a.Wi;
-  const int ostride = Do * Ho * Wo;
-  const long osample = (long)a.Cout * ostride;
-  int bufA = 0, bufB = 0;
   f32x16 acc[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
+  const int my_tiles = (t_end - t_begin + t_step - 1) / t_step;
+  const int nslots = 2 * my_tiles * S;
+  // slot k: half-group 0 computes at even k and is in its load slot at odd k; half-group 1 the other way round
 #pragma unroll 1
-  while (cur.tile < t_end) {
-    const int kd = step_kd(cur.s);
-    const char* ab = a_lds + bufA * A_SLAB + lane * 16;
-    const char* bb = b_lds + bufB * B_IMG + boff + (kd == 0 ? IH * IW * 16 : 0);   // taps kd = 0 read x[m + 1] along d
-    // the four (h, w) neighbours x[m + delta] of this lane's position, raw fp32; each is split right before the taps
-    // that use it.  Taps are visited grouped by neighbour: delta 3 (tap 0), 2 (taps 1, 2), 1 (taps 3, 6), 0 (4, 5, 7, 8).
-    float4 raw[4][2];
+  for (int k = 0; k < nslots; ++k) {
+    DX3_MARK(0);
+    if (((k + grp) & 1) == 0) {
+      // ---- compute slot: fragment reads, in-register split, 54 MFMAs.  The computing wave outranks its loading partner
+      // on the SIMD's vector issue (waves 4-7 otherwise lose the age arbitration and run ~12 % longer slots).
+      __builtin_amdgcn_s_setprio(1);
+      const int kd = step_kd(cur.s);
+      const char* ab = a_lds + cur.pa * A_SLAB + lane * 16;
+      const char* bb = b_lds + cur.pb * B_IMG + boff + (kd == 0 ? IH * IW * 16 : 0);   // taps kd = 0 read x[m + 1] along d
+      // the four (h, w) neighbours x[m + delta] of this lane's position, raw fp32.  Taps are visited grouped by neighbour --
+      // delta 0 (taps 4, 5, 7, 8), 1 (3, 6), 2 (1, 2), 3 (0).  Only the high term of the first neighbour is built before
+      // the first MFMA; its other two terms and the neighbours still to come are split beside the MFMAs of the first seven
+      // taps, two channel pairs (22 vector instructions) per tap: under 5 per MFMA gap.
+      float4 raw[4][2];
 #pragma unroll
-    for (int dlt = 0; dlt < ((DX3_ABL & 16) ? 1 : 4); ++dlt) {
-      raw[dlt][0] = *(const float4*)(bb + ((dlt >> 1) * IW + (dlt & 1)) * 16);
-      raw[dlt][1] = *(const float4*)(bb + ((dlt >> 1) * IW + (dlt & 1)) * 16 + B_PLANE);
-    }
-    constexpr int TAPS[9] = {0, 1, 2, 3, 6, 4, 5, 7, 8};
-    dx_bf16x8 fa[2][3], fb[3];
-#pragma unroll
-    for (int term = 0; term < 3; ++term) fa[0][term] = *(const dx_bf16x8*)(ab + (TAPS[0] * 3 + term) * 1024);
-    const Cursor nxt = c1;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-      const int tap9 = TAPS[i];
-      if (i == 4) {   // middle of the step: next step's data -> the idle buffers, request the step after
-        if (c1.tile < t_end && !(DX3_ABL & 2)) {
-          store_A(bufA ^ 1);
-          if (step_newb(c1.s)) store_B(bufB ^ 1);
-        }
-        if (c2.tile < t_end && !(DX3_ABL & 2)) {
-          load_A(c2.s);
-          if (step_newb(c2.s)) load_B(c2.n, c2.d0, c2.h0, c2.w0, step_chunk(c2.s));
-        }
-        c1 = c2;
-        advance(c2);
+      for (int dlt = 0; dlt < 4; ++dlt) {
+        raw[dlt][0] = *(const float4*)(bb + ((dlt >> 1) * IW + (dlt & 1)) * 16);
+        raw[dlt][1] = *(const float4*)(bb + ((dlt >> 1) * IW + (dlt & 1)) * 16 + B_PLANE);
       }
-      const int cs = i & 1;
-      if (i < 8 && !(DX3_ABL & 8)) {
+      constexpr int TAPS[9] = {4, 5, 7, 8, 3, 6, 1, 2, 0};
+      constexpr int SLOT[9] = {0, 0, 0, 0, 1, 1, 2, 2, 0};          // fragment slot a tap multiplies with
+      constexpr int SPLIT_D[7] = {0, 1, 1, 2, 2, 3, 3};             // neighbour split beside tap i < 7 ...
+      constexpr int SPLIT_S[7] = {0, 1, 1, 2, 2, 0, 0};             // ... into this slot
+      dx_bf16x8 fa[2][3];
+      u32x4 fw[3][3];                                               // [slot][term]
 #pragma unroll
-        for (int term = 0; term < 3; ++term)
-          fa[cs ^ 1][term] = *(const dx_bf16x8*)(ab + (TAPS[i + 1] * 3 + term) * 1024);
-      }
-      const int kh = tap9 / 3, kw = tap9 % 3;
-      const int pc = (kh != 1) * 2 + (kw != 1);          // output parity class (h, w) of this pass
-      const int dlt = (kh == 0) * 2 + (kw == 0);         // coarse neighbour x[m + delta] (h, w)
-      if (i == 0 || i == 1 || i == 3 || i == 5) dx_split8(raw[(DX3_ABL & 16) ? 0 : dlt][0], raw[(DX3_ABL & 16) ? 0 : dlt][1], fb);
-      // smallest terms first
-      constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
-      if (!(DX3_ABL & 1)) {
+      for (int term = 0; term < 3; ++term) fa[0][term] = *(const dx_bf16x8*)(ab + (TAPS[0] * 3 + term) * 1024);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dx_split_h(raw[0][0], raw[0][1], j, fw[0][0]);
+      // register double buffer for the weight fragments: the three reads of the next tap are issued in front of the six
+      // MFMAs of this one (sched_barrier / sched_group_barrier pin the order; left alone hipcc re-orders the taps, issues
+      // every LDS read right before its first use and waits for it -- with one computing wave per SIMD nothing would hide
+      // that latency)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const int tap9 = TAPS[i], cs = i & 1;
+        if (i < 8) {
+#pragma unroll
+          for (int term = 0; term < 3; ++term)
+            fa[cs ^ 1][term] = *(const dx_bf16x8*)(ab + (TAPS[i + 1] * 3 + term) * 1024);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        const int kh = tap9 / 3, kw = tap9 % 3;
+        const int pc = (kh != 1) * 2 + (kw != 1);          // output parity class (h, w) of this pass
+        if (i == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dx_split_ml(raw[0][0], raw[0][1], j, fw[0][0], fw[0][1], fw[0][2]);
+        } else if (i < 7) {
+          const int d = SPLIT_D[i], sl = SPLIT_S[i], j0 = ((i - 1) & 1) * 2;
+          dx_split_pair(raw[d][0], raw[d][1], j0, fw[sl][0], fw[sl][1], fw[sl][2]);
+          dx_split_pair(raw[d][0], raw[d][1], j0 + 1, fw[sl][0], fw[sl][1], fw[sl][2]);
+        }
+        // smallest terms first -- except in the slot's first tap, which starts with the products of the halo fragment's
+        // high term: that one is ready four instructions after the fragment arrives, the others follow in the MFMA gaps
+        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+        constexpr int PA0[6] = {0, 1, 2, 0, 1, 0}, PB0[6] = {0, 0, 0, 1, 1, 2};
 #pragma unroll
         for (int q = 0; q < 6; ++q)
-          acc[pc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[(DX3_ABL & 8) ? 0 : cs][PA[q]], fb[PB[q]], acc[pc], 0, 0, 0);
-      } else {
-        acc[pc][q0(tap9)] += (float)fa[(DX3_ABL & 8) ? 0 : cs][0][0] * (float)fb[0][0];
-      }
-    }
-    __syncthreads();
-
-    if ((cur.s == a.NCH - 1 || cur.s == S - 1) && (!(DX3_ABL & 4) || a.slope == 123.f)) {
-      // epilogue of the pass: y = act(acc * scale + shift + res_pre) + res_post on output planes 2m + pd; a lane holds
-      // the two w-parities of (h-parity, channel) = 8 contiguous bytes, 16 lanes 128 contiguous bytes
-      const int pd = cur.s == S - 1;
-      const int md = cur.d0 + dl, mh = cur.h0 + hl, mw = cur.w0 + wl;
-      const int ok = (int)(md < a.Di) & (int)(mh < a.Hi) & (int)(mw < a.Wi);
-      const __amdgpu_buffer_rsrc_t yr = dca_rsrc(a.y + (long)cur.n * osample, osample * 4);
-      const __amdgpu_buffer_rsrc_t pr = dca_rsrc((has_pre ? a.res_pre : a.y) + (long)cur.n * osample, osample * 4);
-      const __amdgpu_buffer_rsrc_t qr = dca_rsrc((has_post ? a.res_post : a.y) + (long)cur.n * osample, osample * 4);
+          acc[pc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cs][i == 0 ? PA0[q] : PA[q]],
+                                                            __builtin_bit_cast(dx_bf16x8, fw[SLOT[i]][i == 0 ? PB0[q] : PB[q]]),
+                                                            acc[pc], 0, 0, 0);
+        if (i == 0) {   // high-term products first; the chains of the middle and low terms fill the gaps in that order
 #pragma unroll
-      for (int ph = 0; ph < 2; ++ph) {
-        // channel >= Cout is beyond the descriptor's range: dropped / read as zero by the hardware
-        const int base = dca_pred_off((((2 * md + pd) * Ho + 2 * mh + ph) * Wo + 2 * mw + 4 * half * ostride) * 4, ok);
-#pragma unroll
-        for (int rc = 0; rc < 16; rc += 8) {
-          u32x2 wp[8], wq[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) wp[q] = wq[q] = u32x2{0u, 0u};
-          if (has_pre) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-              const int r = rc + q;
-              wp[q] = __builtin_amdgcn_raw_buffer_load_b64(pr, base + ((r & 3) + 8 * (r >> 2)) * ostride * 4, 0, 0);
-            }
+          for (int q = 0; q < 6; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
           }
-          if (has_post) {
+        } else if (i < 7) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-              const int r = rc + q;
-              wq[q] = __builtin_amdgcn_raw_buffer_load_b64(qr, base + ((r & 3) + 8 * (r >> 2)) * ostride * 4, 0, 0);
-            }
-          }
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            const int r = rc + q, cl = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float sc = aff_lds[cl], sh = aff_lds[32 + cl];
-            const float v0 = act_apply(acc[ph * 2][r] * sc + sh + __uint_as_float(wp[q].x), a.slope) + __uint_as_float(wq[q].x);
-            const float v1 = act_apply(acc[ph * 2 + 1][r] * sc + sh + __uint_as_float(wp[q].y), a.slope) + __uint_as_float(wq[q].y);
-            const u32x2 o = {__float_as_uint(v0), __float_as_uint(v1)};
-            __builtin_amdgcn_raw_buffer_store_b64(o, yr, base + ((r & 3) + 8 * (r >> 2)) * ostride * 4, 0, DX3_NT ? 2 : 0);
+          for (int q = 0; q < 6; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
+      __builtin_amdgcn_s_setprio(0);
+      DX3_MARK(3);
+      if (cur.s == a.NCH - 1 || cur.s == S - 1) {
+        // end of a pass: y = act(acc * scale + shift + res_pre) + res_post on output planes 2m + pd; a lane holds the two
+        // w-parities of (h-parity, channel) = 8 contiguous bytes, 16 lanes 128 contiguous bytes.  With all 32 output
+        // channels present the channel part of a plain store's address is a scalar offset (no vector instruction per store);
+        // otherwise it stays in the vector offset, where the hardware range check drops channels >= Cout.
+        const int pd = cur.s == S - 1;
+        const int md = cur.d0 + dl, mh = cur.h0 + hl, mw = cur.w0 + wl;
+        const int ok = (int)(md < a.Di) & (int)(mh < a.Hi) & (int)(mw < a.Wi);
+        const __amdgpu_buffer_rsrc_t yr = dca_rsrc(a.y + (long)cur.n * osample, osample * 4);
+        const bool plain = !has_aff && !has_pre && !has_post && a.slope == 1.f;
+        if (plain) {
 #pragma unroll
-      for (int p = 0; p < 4; ++p)
+          for (int ph = 0; ph < 2; ++ph) {
+            // channel >= Cout is beyond the descriptor's range: dropped by the hardware
+            const int base = dca_pred_off((((2 * md + pd) * Ho + 2 * mh + ph) * Wo + 2 * mw + 4 * half * ostride) * 4, ok);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+              const u32x2 o = {__float_as_uint(acc[ph * 2][r]), __float_as_uint(acc[ph * 2 + 1][r])};
+              const int coff = ((r & 3) + 8 * (r >> 2)) * ostride * 4;
+              if (cout_full) __builtin_amdgcn_raw_buffer_store_b64(o, yr, base, coff, DX3_NT ? 2 : 0);
+              else __builtin_amdgcn_raw_buffer_store_b64(o, yr, base + coff, 0, DX3_NT ? 2 : 0);
+            }
+          }
+        } else {
+          const __amdgpu_buffer_rsrc_t pr = dca_rsrc((has_pre ? a.res_pre : a.y) + (long)cur.n * osample, osample * 4);
+          const __amdgpu_buffer_rsrc_t qr = dca_rsrc((has_post ? a.res_post : a.y) + (long)cur.n * osample, osample * 4);
+#pragma unroll
+          for (int ph = 0; ph < 2; ++ph) {
+            const int base = dca_pred_off((((2 * md + pd) * Ho + 2 * mh + ph) * Wo + 2 * mw + 4 * half * ostride) * 4, ok);
+#pragma unroll
+            for (int rc = 0; rc < 16; rc += 8) {
+              u32x2 wp[8], wq[8];
+#pragma unroll
+              for (int q = 0; q < 8; ++q) wp[q] = wq[q] = u32x2{0u, 0u};
+              if (has_pre) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                  const int r = rc + q;
+                  wp[q] = __builtin_amdgcn_raw_buffer_load_b64(pr, base + ((r & 3) + 8 * (r >> 2)) * ostride * 4, 0, 0);
+                }
+              }
+              if (has_post) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                  const int r = rc + q;
+                  wq[q] = __builtin_amdgcn_raw_buffer_load_b64(qr, base + ((r & 3) + 8 * (r >> 2)) * ostride * 4, 0, 0);
+                }
+              }
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                const int r = rc + q, cl = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float sc = aff_lds[cl], sh = aff_lds[32 + cl];
+                const float v0 = act_apply(acc[ph * 2][r] * sc + sh + __uint_as_float(wp[q].x), a.slope) + __uint_as_float(wq[q].x);
+                const float v1 = act_apply(acc[ph * 2 + 1][r] * sc + sh + __uint_as_float(wp[q].y), a.slope) + __uint_as_float(wq[q].y);
+                const u32x2 o = {__float_as_uint(v0), __float_as_uint(v1)};
+                __builtin_amdgcn_raw_buffer_store_b64(o, yr, base + ((r & 3) + 8 * (r >> 2)) * ostride * 4, 0, DX3_NT ? 2 : 0);
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+      }
+      DX3_MARK(2);
+      advance(cur);
+    } else {
+      // ---- load slot: this half-group's share of the next step -> LDS, request the step after
+#if DX3_STAMP
+      __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+      DX3_MARK(4);
+#endif
+      if (st.tile < t_end) {
+        store_A(st.pa);
+        if (step_newb(st.s)) store_B(st.pb);
+      }
+      DX3_MARK(1);
+      if (ld.tile < t_end) {
+        load_A(ld.s);
+        if (step_newb(ld.s)) load_B(ld.n, ld.d0, ld.h0, ld.w0, step_chunk(ld.s));
+      }
+      st = ld;
+      advance(ld);
+      DX3_MARK(3);
     }
-    bufA ^= 1;
-    if (nxt.tile < t_end && step_newb(nxt.s)) bufB ^= 1;
-    cur = nxt;
+    __syncthreads();
+    DX3_MARK(5);
   }
 }
 

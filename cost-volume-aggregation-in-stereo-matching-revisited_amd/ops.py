@@ -287,6 +287,7 @@ def _round_up(a, m):
 # at 1.3-1.75x the speed on every shape the networks use, 1/4 to 1/16 resolution (tools/x3_vs_fp32.py).
 # DCA_CONV=fp32 forces the fp32 MFMA kernel everywhere.
 CONV_X3 = os.environ.get("DCA_CONV", "x3") != "fp32"
+DECONV_X3 = os.environ.get("DCA_DECONV", "x3") != "fp32"   # the transposed-convolution member of the family alone (A/B timing)
 _X3_MIN_WORKGROUPS = 1
 
 
@@ -301,7 +302,7 @@ def _x3_eligible(x, x2, ksize, stride, transposed, A, B):
 def _dx3_eligible(x, x2, ksize, stride, transposed, A, B):
     """transposed 3x3x3 stride-2 convs on the bf16x3 kernel of deconv3d_x3.hip: <= 32 output channels, coarse width
     divisible by 4, 16-byte aligned input"""
-    if not CONV_X3 or not transposed or ksize != 3 or stride != 2 or x2 is not None or B > 32 or A > 64:
+    if not CONV_X3 or not DECONV_X3 or not transposed or ksize != 3 or stride != 2 or x2 is not None or B > 32 or A > 64:
         return False
     N, _, D, H, W = x.shape
     return W % 4 == 0 and x.data_ptr() % 16 == 0 and max(A, 8) * D * H * W * 4 < 0x7ffffff0 and 256 * D * H * W * 4 < 0x7ffffff0

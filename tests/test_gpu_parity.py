@@ -210,6 +210,7 @@ DX3_CASES = [
     (64, 32, (5, 9, 20), 2),
     (32, 32, (3, 4, 8), 1),
     (40, 27, (3, 8, 16), 1),
+    (40, 27, (3, 8, 16), 2),
     (16, 32, (2, 9, 12), 3),
     (64, 32, (7, 17, 32), 1),
 ]
@@ -236,6 +237,18 @@ def test_deconv3d_bf16x3(case, monkeypatch):
     e32 = (ops.conv3d(xg, wg, 2, True).cpu().double() - ref).abs().max().item()
     monkeypatch.setattr(ops, "CONV_X3", True)
     assert (y.cpu().double() - ref).abs().max().item() <= 2.0 * max(e32, 1e-7 * ref.abs().max().item())
+    # nothing may be written outside y (channels >= Cout of the 32-channel MFMA block are dropped by the hardware range
+    # check): call the C ABI on a y that sits inside a sentinel-filled buffer
+    lib = ops._L()
+    wx = torch.empty((lib.dca_conv3d_x3_weight_bytes(cin, cout) // 2,), device=DEV, dtype=torch.int16)
+    ops._chk(lib.dca_conv3d_x3_prep_weight(ops._ptr(wg), ops._ptr(wx), cin, cout, 1, 0, ops._stream()), "prep")
+    pad = 4096
+    big = torch.full((ref.numel() + 2 * pad,), 777.0, device=DEV)
+    yv = big[pad:pad + ref.numel()]
+    ops._chk(lib.dca_deconv3d_x3_forward(ops._ptr(xg), ops._ptr(wx), ops._ptr(yv), None, None, None, None, 1.0, N, cin, cout,
+                                         dims[0], dims[1], dims[2], ops._stream()), "dca_deconv3d_x3_forward")
+    assert torch.equal(yv.view(ref.shape), y), "direct C-ABI call differs from the op"
+    assert bool((big[:pad] == 777.0).all()) and bool((big[pad + ref.numel():] == 777.0).all()), "wrote outside y"
     # fused epilogue: relu(y * scale + shift + res_pre) + res_post
     sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
     rp, rq = torch.randn(ref.shape, generator=g), torch.randn(ref.shape, generator=g)
