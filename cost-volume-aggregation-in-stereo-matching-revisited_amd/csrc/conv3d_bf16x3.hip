@@ -26,11 +26,14 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// Non-temporal output stores: y is written once, so it should not displace the halo lines the neighbouring tiles re-read
-// from this XCD's L2 -- 591 -> 568 us on the fused-epilogue 32->32 launch at 48x136x240 (tools/nt_ablate.sh).  (The same
-// switch on the reduced-precision kernel's 4-byte pair stores is a loss, 118 -> 150 us: partial lines.)
+// Non-temporal output stores (X3_NT=1): y is written once, so it need not displace the halo lines the neighbouring tiles
+// re-read from this XCD's L2 -- 591 -> 568 us on the fused-epilogue 32->32 launch at 48x136x240 in isolation
+// (tools/nt_ablate.sh).  In the network the consumer of y (BatchNorm statistics + apply in training, the next convolution
+// in inference) runs right behind and finds a 200 MB output partly in the 256 MB infinity cache when it was stored with
+// the default policy: training step 37.86 -> 37.38 ms per pair at batch 1, eval forward 7.63 -> 7.51 ms, batch-4 step
+// 143.7 -> 143.4 ms (tools/nt_bench_ab.sh).  So the default is plain stores.
 #ifndef X3_NT
-#define X3_NT 1
+#define X3_NT 0
 #endif
 
 namespace {

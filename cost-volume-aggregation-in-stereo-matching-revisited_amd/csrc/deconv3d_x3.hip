@@ -37,8 +37,9 @@
 
 typedef __bf16 dx_bf16x8 __attribute__((ext_vector_type(8)));
 
+// non-temporal output stores: off, as in conv3d_bf16x3.hip (the consumer finds y in the infinity cache)
 #ifndef DX3_NT
-#define DX3_NT 1
+#define DX3_NT 0
 #endif
 #ifndef DX3_SOFF
 #define DX3_SOFF 1
