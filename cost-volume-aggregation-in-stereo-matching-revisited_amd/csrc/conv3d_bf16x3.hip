@@ -65,7 +65,20 @@ struct X3Args {
   int N, Cin, Cout, NCH;
   int D, H, W;
   int nTD, nTH, nTW;
+  const float* stat_shift;   // STATS: per-channel shift K_c (the BatchNorm running mean), Cout floats
+  double* stat_part;         // STATS: part[(c*nchunk + i)*2 + {0,1}] partial sums of (y - K_c), (y - K_c)^2; K_c at the end
 };
+
+constexpr int STAT_LDS = 8 * 4 * 16 * 2 * 4 + 128;   // [wave][16-lane row][r][sum, sum of squares] floats + 32 shifts
+
+// sum over the 16 lanes of a DPP row, result in every lane of the row
+__device__ __forceinline__ float row16_sum(float x) {
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xF, 0xF, true));   // row_mirror
+  return x;
+}
 
 __device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l) {
   h = (__bf16)v;
@@ -75,11 +88,17 @@ __device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l)
   l = (__bf16)r2;
 }
 
-template <bool VEC>
+// STATS: the raw convolution output feeds a training-mode BatchNorm -- the kernel also produces the per-channel partial
+// sums of (y - K_c) and (y - K_c)^2 that dca_bn_finalize consumes (the layout of dca_bn_stats, nchunk = 2 * gridDim.x:
+// one partial per workgroup and row parity), so the 200 MB statistics pass over y disappears.  Per tile: 3 vector
+// instructions per output value, a 4-step DPP reduction over the 16 positions of a row, one ds_add_f32 per (row, channel)
+// into a wave-private LDS slot; fixed order, no atomics between waves: bitwise reproducible.
+template <bool VEC, bool STATS>
 __global__ __launch_bounds__(512) void conv3_bf16x3_kernel(X3Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* b_lds = smem;
   char* a_lds = smem + B_BYTES;
+  float* stat_lds = (float*)(smem + LDS_BYTES);     // STATS only (the launch adds STAT_LDS bytes)
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, half = lane >> 5;
   const int cblk = blockIdx.y;
@@ -91,7 +110,32 @@ __global__ __launch_bounds__(512) void conv3_bf16x3_kernel(X3Args a) {
   const int nx = gridDim.x >= 8 ? 8 : 1, xcd = blockIdx.x % nx;
   const int cnt = (gridDim.x - xcd + nx - 1) / nx;          // workgroups on this XCD
   const int t_begin = (int)(T * xcd / nx) + blockIdx.x / nx, t_end = (int)(T * (xcd + 1) / nx), t_step = cnt;
-  if (t_begin >= t_end) return;
+  const int stat_nchunk = 2 * gridDim.x;
+  if constexpr (STATS) {
+    // this wave's 4 x 16 x 2 accumulators, and the shifts of this channel block
+    for (int i = lane; i < 128; i += 64) stat_lds[wv * 128 + i] = 0.f;
+    if (tid < 32) stat_lds[1024 + tid] = (cblk * 32 + tid < a.Cout) ? a.stat_shift[cblk * 32 + tid] : 0.f;
+    if (blockIdx.x == 0 && tid < 32 && cblk * 32 + tid < a.Cout)
+      a.stat_part[(long)a.Cout * stat_nchunk * 2 + cblk * 32 + tid] = (double)a.stat_shift[cblk * 32 + tid];
+    __syncthreads();
+  }
+  auto flush_stats = [&]() __attribute__((always_inline)) {
+    // slot (row = lane >> 4, r) summed over the eight waves in wave order: channel cblk*32 + cu(r) + 4*(row >> 1), partial
+    // index blockIdx.x*2 + (row & 1)
+    __syncthreads();
+    if (tid < 128) {
+      const int i = tid, pair = i & 1, r = (i >> 1) & 15, row = i >> 5;
+      const int c = cblk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (row >> 1);
+      float sum = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) sum += stat_lds[w8 * 128 + i];
+      if (c < a.Cout) a.stat_part[((long)c * stat_nchunk + blockIdx.x * 2 + (row & 1)) * 2 + pair] = (double)sum;
+    }
+  };
+  if (t_begin >= t_end) {
+    if constexpr (STATS) flush_stats();
+    return;
+  }
 
   // per-lane byte offset of the lane's voxel inside a term image, for its two column tiles
   // ds_read_b128 is served in four NON-contiguous 16-lane groups ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...:
@@ -328,6 +372,11 @@ __global__ __launch_bounds__(512) void conv3_bf16x3_kernel(X3Args a) {
       sc[r] = has_aff ? a.scale[co] : 1.f;
       sh[r] = has_aff ? a.shift[co] : 0.f;
     }
+    float st_s[STATS ? 16 : 1], st_q[STATS ? 16 : 1];
+    if constexpr (STATS) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st_s[r] = st_q[r] = 0.f;
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int r0 = (wv * 2 + t) * 2 + (l31 >> 4), d = d0 + (r0 >> 3), h = h0 + (r0 & 7), w = w0 + wlane;
@@ -355,6 +404,11 @@ __global__ __launch_bounds__(512) void conv3_bf16x3_kernel(X3Args a) {
         if (has_pre) v += rp[r];
         v = act_apply(v, a.slope);
         if (has_post) v += rq[r];
+        if constexpr (STATS) {
+          const float dlt = ok ? v - stat_lds[1024 + cu + 4 * half] : 0.f;
+          st_s[r] += dlt;
+          st_q[r] = fmaf(dlt, dlt, st_q[r]);
+        }
 #if X3_NT
         dca_bstore1_nt(yr, v, voff + cu * cstride * 4, ok & (int)(cblk * 32 + cu + 4 * half < a.Cout));
 #else
@@ -362,8 +416,20 @@ __global__ __launch_bounds__(512) void conv3_bf16x3_kernel(X3Args a) {
 #endif
       }
     }
+    if constexpr (STATS) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float rs = row16_sum(st_s[r]), rq2 = row16_sum(st_q[r]);
+        if ((lane & 15) == 0) {
+          float* slot = stat_lds + wv * 128 + ((lane >> 4) * 16 + r) * 2;
+          slot[0] += rs;      // wave-private slot, one writer lane per slot
+          slot[1] += rq2;
+        }
+      }
+    }
     n = nn; d0 = nd0; h0 = nh0; w0 = nw0;
   }
+  if constexpr (STATS) flush_stats();
 }
 
 // wx[cblk][chunk][tap][term][lane][j] (bf16): lane (r = lane & 31, h = lane >> 5) holds A[row = output channel
@@ -409,9 +475,25 @@ extern "C" int dca_conv3d_x3_prep_weight(const float* w, void* wx, int A, int B,
   return dca_launch_status();
 }
 
-extern "C" int dca_conv3d_x3_forward(const float* x, const void* wx, float* y, const float* scale, const float* shift,
-                                     const float* res_pre, const float* res_post, float slope, int N, int Cin, int Cout,
-                                     int D, int H, int W, hipStream_t stream) {
+namespace {
+
+int x3_grid(long tiles, int cblks) {
+  // persistent: one workgroup per CU (the LDS footprint allows no more), each looping over its share of the tiles
+  int ncu = 256;   // per device, so not cached in a static
+  {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      ncu = v;
+  }
+  int gx = ncu / cblks > 0 ? ncu / cblks : 1;
+  if (gx > tiles) gx = (int)tiles;
+  return gx;
+}
+
+int x3_launch(const float* x, const void* wx, float* y, const float* scale, const float* shift, const float* res_pre,
+              const float* res_post, float slope, const float* stat_shift, double* stat_part, int N, int Cin, int Cout,
+              int D, int H, int W, hipStream_t stream) {
   DCA_REQUIRE(x && wx && y && N > 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0);
   DCA_REQUIRE((scale == nullptr) == (shift == nullptr));
   DCA_REQUIRE((long)Cin * D * H * W * 4 < 0x7ffffff0L && (long)Cout * D * H * W * 4 < 0x7ffffff0L);  // 32-bit byte offsets inside one sample
@@ -422,24 +504,41 @@ extern "C" int dca_conv3d_x3_forward(const float* x, const void* wx, float* y, c
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.NCH = (Cin + 15) / 16;
   a.D = D; a.H = H; a.W = W;
   a.nTD = cdiv(D, TD); a.nTH = cdiv(H, TH); a.nTW = cdiv(W, TW);
+  a.stat_shift = stat_shift; a.stat_part = stat_part;
   const long tiles = (long)N * a.nTD * a.nTH * a.nTW;
   DCA_REQUIRE(tiles < 0x7fffffffL && (Cout + 31) / 32 <= 65535);
-  // per device, so not cached in a static
   const bool vec = (W % 4 == 0) && ((((uintptr_t)x) & 15) == 0);
-  auto kern = vec ? conv3_bf16x3_kernel<true> : conv3_bf16x3_kernel<false>;
-  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  const bool stats = stat_part != nullptr;
+  auto kern = stats ? (vec ? conv3_bf16x3_kernel<true, true> : conv3_bf16x3_kernel<false, true>)
+                    : (vec ? conv3_bf16x3_kernel<true, false> : conv3_bf16x3_kernel<false, false>);
+  const int lds = LDS_BYTES + (stats ? STAT_LDS : 0);
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return (int)e;
-  // persistent: one workgroup per CU (the LDS footprint allows no more), each looping over its share of the tiles
   const int cblks = (Cout + 31) / 32;
-  int ncu = 256;
-  {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-      ncu = v;
-  }
-  int gx = ncu / cblks > 0 ? ncu / cblks : 1;
-  if (gx > tiles) gx = (int)tiles;
-  hipLaunchKernelGGL(kern, dim3(gx, cblks), dim3(512), LDS_BYTES, stream, a);
+  hipLaunchKernelGGL(kern, dim3(x3_grid(tiles, cblks), cblks), dim3(512), lds, stream, a);
   return dca_launch_status();
+}
+
+}  // namespace
+
+extern "C" int dca_conv3d_x3_forward(const float* x, const void* wx, float* y, const float* scale, const float* shift,
+                                     const float* res_pre, const float* res_post, float slope, int N, int Cin, int Cout,
+                                     int D, int H, int W, hipStream_t stream) {
+  return x3_launch(x, wx, y, scale, shift, res_pre, res_post, slope, nullptr, nullptr, N, Cin, Cout, D, H, W, stream);
+}
+
+// nchunk of the statistics dca_conv3d_x3_forward_stats produces (2 per workgroup of the launch it will make)
+extern "C" long dca_conv3d_x3_stats_chunks(int N, int Cout, int D, int H, int W) {
+  if (N <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+  const long tiles = (long)N * cdiv(D, TD) * cdiv(H, TH) * cdiv(W, TW);
+  return 2L * x3_grid(tiles, (Cout + 31) / 32);
+}
+
+// y = conv(x, w) (no epilogue) plus the BatchNorm batch statistics of y: part (Cout*nchunk*2 + Cout doubles, nchunk =
+// dca_conv3d_x3_stats_chunks) in the layout of dca_bn_stats with K_c = stat_shift[c], ready for dca_bn_finalize
+extern "C" int dca_conv3d_x3_forward_stats(const float* x, const void* wx, float* y, const float* stat_shift,
+                                           double* stat_part, int N, int Cin, int Cout, int D, int H, int W,
+                                           hipStream_t stream) {
+  DCA_REQUIRE(stat_shift && stat_part);
+  return x3_launch(x, wx, y, nullptr, nullptr, nullptr, nullptr, 1.f, stat_shift, stat_part, N, Cin, Cout, D, H, W, stream);
 }

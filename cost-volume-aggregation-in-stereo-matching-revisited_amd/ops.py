@@ -287,7 +287,8 @@ def _round_up(a, m):
 # at 1.3-1.75x the speed on every shape the networks use, 1/4 to 1/16 resolution (tools/x3_vs_fp32.py).
 # DCA_CONV=fp32 forces the fp32 MFMA kernel everywhere.
 CONV_X3 = os.environ.get("DCA_CONV", "x3") != "fp32"
-DECONV_X3 = os.environ.get("DCA_DECONV", "x3") != "fp32"   # the transposed-convolution member of the family alone (A/B timing)
+DECONV_X3 = os.environ.get("DCA_DECONV", "x3") != "fp32"
+BN_FUSE = os.environ.get("DCA_BN_FUSE", "1") != "0"        # BatchNorm batch statistics from the conv epilogue (training)   # the transposed-convolution member of the family alone (A/B timing)
 _X3_MIN_WORKGROUPS = 1
 
 
@@ -560,6 +561,48 @@ class _Conv3d(torch.autograd.Function):
         return gx, gx2, gw, None, None
 
 
+class _Conv3dStats(torch.autograd.Function):
+    """Conv3d(k=3, s=1, p=1, bias=False) on the bf16x3 kernel, which also emits the BatchNorm batch statistics of its
+    output (dca_conv3d_x3_forward_stats): returns (y, part); `shift` = per-channel shift of the sums (the running mean)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, shift):
+        x, weight = _req(x, "conv3d"), _req(weight, "conv3d.weight")
+        N, Cin, D, H, W = x.shape
+        Cout = weight.shape[0]
+        lib = _L()
+        with torch.cuda.device_of(x):
+            def build_x3():
+                w3 = torch.empty((lib.dca_conv3d_x3_weight_bytes(Cin, Cout) // 2,), device=x.device, dtype=torch.int16)
+                _chk(lib.dca_conv3d_x3_prep_weight(_ptr(weight), _ptr(w3), Cin, Cout, 0, 0, _stream()),
+                     "dca_conv3d_x3_prep_weight")
+                return w3
+            wx = _memo(("x3prep", Cin, Cout, 0, 0), (weight,), build_x3, (1, Cin, Cout, 0, 0, 27, 0, 0, Cout, 0))
+            y = torch.empty((N, Cout, D, H, W), device=x.device, dtype=torch.float32)
+            nchunk = lib.dca_conv3d_x3_stats_chunks(N, Cout, D, H, W)
+            part = torch.empty((Cout * nchunk * 2 + Cout,), device=x.device, dtype=torch.float64)
+            shift = _req(shift.detach(), "conv3d.stat_shift")
+            _chk(lib.dca_conv3d_x3_forward_stats(_ptr(x), _ptr(wx), _ptr(y), _ptr(shift), _ptr(part), N, Cin, Cout, D, H, W,
+                                                 _stream()), "dca_conv3d_x3_forward_stats")
+        ctx.save_for_backward(x, weight)
+        ctx.mark_non_differentiable(part)
+        return y, part
+
+    @staticmethod
+    def backward(ctx, dy, _dpart):
+        x, weight = ctx.saved_tensors
+        dy = _req(dy, "conv3d.backward")
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        gx = gw = None
+        with torch.cuda.device_of(x):
+            if ctx.needs_input_grad[0]:
+                gx = _conv_sliced(dy, None, weight, Cout, Cin, 27, 1, 1, 3, 1, False)
+            if ctx.needs_input_grad[1]:
+                gw = torch.empty_like(weight)
+                _wgrad(x, dy, gw, 0, Cin, Cout, 3, 1, Cin * 27, 27)
+        return gx, gw, None
+
+
 def conv3d(x, weight, stride=1, transposed=False, x2=None):
     if (not transposed and x2 is None and weight.shape[0] == 1 and weight.shape[2] == 3 and int(stride) == 1
             and weight.shape[1] in (32, 64)):
@@ -578,16 +621,20 @@ def conv3d_fused_inference(x, weight, stride, transposed, scale, shift, slope, r
 # ------------------------------------------------------------------------------------------------
 # BatchNorm3d + activation + residual
 # ------------------------------------------------------------------------------------------------
-def bn_stats_vector(y, gamma, beta, running_mean, running_var, training, momentum, eps):
-    """[mean | invstd | scale | shift] (4*C floats); updates the running stats in place when training."""
+def bn_stats_vector(y, gamma, beta, running_mean, running_var, training, momentum, eps, part=None):
+    """[mean | invstd | scale | shift] (4*C floats); updates the running stats in place when training.
+    part: partial sums the producing convolution already emitted (dca_conv3d_x3_forward_stats), or None."""
     N, C = y.shape[0], y.shape[1]
     S = y[0, 0].numel()
     stats = torch.empty((4 * C,), device=y.device, dtype=torch.float32)
     lib = _L()
     if training:
-        nchunk = lib.dca_bn_num_chunks(C, S)
-        part = torch.empty((C * nchunk * 2 + C,), device=y.device, dtype=torch.float64)   # partial sums + C shifts
-        _chk(lib.dca_bn_stats(_ptr(y), _ptr(part), N, C, S, _stream()), "dca_bn_stats")
+        if part is not None:
+            nchunk = (part.numel() - C) // (2 * C)
+        else:
+            nchunk = lib.dca_bn_num_chunks(C, S)
+            part = torch.empty((C * nchunk * 2 + C,), device=y.device, dtype=torch.float64)   # partial sums + C shifts
+            _chk(lib.dca_bn_stats(_ptr(y), _ptr(part), N, C, S, _stream()), "dca_bn_stats")
         _chk(lib.dca_bn_finalize(_ptr(part), nchunk, float(N * S), _ptr(gamma), _ptr(beta), _ptr(running_mean),
                                  _ptr(running_var), float(momentum), float(eps), 1, _ptr(stats), C, _stream()),
              "dca_bn_finalize")
@@ -616,13 +663,14 @@ class _BnAct(torch.autograd.Function):
     """z = act(BN(y) + res_pre) + res_post with nn.BatchNorm3d semantics."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, training, momentum, eps, slope, res_pre, res_post):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, training, momentum, eps, slope, res_pre, res_post,
+                part=None):
         y = _req(y, "batch_norm")
         res_pre, res_post = _opt(res_pre, "res_pre"), _opt(res_post, "res_post")
         N, C = y.shape[0], y.shape[1]
         S = y[0, 0].numel()
         with torch.cuda.device_of(y):
-            stats = bn_stats_vector(y, gamma, beta, running_mean, running_var, training, momentum, eps)
+            stats = bn_stats_vector(y, gamma, beta, running_mean, running_var, training, momentum, eps, part)
             z = torch.empty_like(y)
             _chk(_L().dca_bn_apply(_ptr(y), _ptr(stats), _ptr(res_pre), _ptr(res_post), _ptr(z), N, C, S, float(slope),
                                    _stream()), "dca_bn_apply")
@@ -651,7 +699,7 @@ class _BnAct(torch.autograd.Function):
         if has_pre and ctx.needs_input_grad[9]:
             g_pre = g_out if want_g else dz
         g_post = dz if (has_post and ctx.needs_input_grad[10]) else None
-        return dy, dgb[:C], dgb[C:2 * C], None, None, None, None, None, None, g_pre, g_post
+        return dy, dgb[:C], dgb[C:2 * C], None, None, None, None, None, None, g_pre, g_post, None
 
 
 _tls = threading.local()
@@ -787,14 +835,15 @@ class batched_bn_counters:
         return False
 
 
-def bn_act(y, bn, slope=1.0, res_pre=None, res_post=None):
-    """Applies the nn.BatchNorm3d module `bn` (parameters/buffers only; its forward is never called)."""
+def bn_act(y, bn, slope=1.0, res_pre=None, res_post=None, stats_part=None):
+    """Applies the nn.BatchNorm3d module `bn` (parameters/buffers only; its forward is never called).
+    stats_part: batch-statistics partial sums of y from the producing convolution (`_Conv3dStats`), if it made them."""
     momentum = 0.1 if bn.momentum is None else bn.momentum
     training = bn.training or bn.running_mean is None
     if _lp_dtype() is not None:
         raise RuntimeError("ops.reduced_precision is inference only: call the model in eval mode under torch.no_grad()")
     z = _BnAct.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, float(slope),
-                     res_pre, res_post)
+                     res_pre, res_post, stats_part if training else None)
     if bn.training and bn.num_batches_tracked is not None:
         pending = getattr(_tls, "pending", None)
         if pending is not None:
@@ -852,6 +901,13 @@ def convbn3d(x, conv, bn, slope=1.0, res_pre=None, res_post=None, x2=None):
         C = bn.num_features
         return conv3d_fused_inference(xx, conv.weight, stride, transposed, stats[2 * C:3 * C], stats[3 * C:], slope,
                                       res_pre, res_post, x2)
+    if (BN_FUSE and bn.training and bn.running_mean is not None and not transposed and stride == 1 and x2 is None
+            and conv.kernel_size[0] == 3 and conv.weight.shape[0] > 1 and _lp_dtype() is None and x.is_cuda
+            and x.dtype == torch.float32 and x.is_contiguous()
+            and _x3_eligible(x, None, 3, 1, False, conv.weight.shape[1], conv.weight.shape[0])):
+        # the convolution kernel emits the batch statistics of its own output: no separate pass over y
+        y, part = _Conv3dStats.apply(x, conv.weight, bn.running_mean)
+        return bn_act(y, bn, slope, res_pre, res_post, part)
     y = conv3d(x, conv.weight, stride, transposed, x2)
     return bn_act(y, bn, slope, res_pre, res_post)
 

@@ -23,7 +23,7 @@ extern "C" {
 
 /* Bumped whenever an argument list below changes; the ctypes loader (_lib.py) refuses a library built from another
  * version of this header. */
-#define DCA_ABI_VERSION 6
+#define DCA_ABI_VERSION 7
 int dca_abi_version(void);
 
 /* storage types of the reduced-precision inference path (0 = fp32) */
@@ -154,6 +154,15 @@ int dca_conv3d_x3_forward(const float* x, const void* wx, float* y, const float*
 int dca_deconv3d_x3_forward(const float* x, const void* wx, float* y, const float* scale, const float* shift,
                             const float* res_pre, const float* res_post, float slope, int N, int Cin, int Cout, int Di,
                             int Hi, int Wi, hipStream_t stream);
+
+/* The same convolution without epilogue, fused with the BatchNorm batch statistics of its output (training-mode
+ * convbn_3d, models/submodule.py:121-124): part (Cout*nchunk*2 + Cout doubles, nchunk = dca_conv3d_x3_stats_chunks(...))
+ * receives, in the layout of dca_bn_stats, the per-(workgroup, wave, row) partial sums of (y - K_c) and (y - K_c)^2 with
+ * K_c = stat_shift[c] (the caller passes the BatchNorm running mean), ready for dca_bn_finalize(part, nchunk, N*D*H*W, ...).
+ * Fixed summation order: bitwise reproducible. */
+long dca_conv3d_x3_stats_chunks(int N, int Cout, int D, int H, int W);
+int dca_conv3d_x3_forward_stats(const float* x, const void* wx, float* y, const float* stat_shift, double* stat_part,
+                                int N, int Cin, int Cout, int D, int H, int W, hipStream_t stream);
 
 /* Weight gradient of the 3x3x3 / stride-1 / pad-1 convolution on the bf16 matrix pipe with the same exact three-way
  * bf16 split (conv3d_wgrad_bf16x3.hip); replaces dca_conv3d_wgrad for ksize 3, stride 1 (autograd's dW of the nn.Conv3d

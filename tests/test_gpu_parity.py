@@ -268,6 +268,73 @@ def test_deconv3d_bf16x3(case, monkeypatch):
     assert (gx.cpu().double() - gxr).abs().max().item() <= 2e-6 * gxr.abs().max().item()
 
 
+STATS_CASES = [
+    # cin, cout, dims, N
+    (32, 32, (5, 10, 36), 2),
+    (40, 27, (4, 6, 20), 1),
+    (16, 64, (3, 9, 17), 2),      # two channel blocks, single-voxel staging path
+    (32, 32, (9, 17, 33), 1),
+    (32, 32, (1, 2, 4), 1),       # fewer tiles than workgroups
+]
+
+
+@pytest.mark.parametrize("case", STATS_CASES, ids=[str(c) for c in STATS_CASES])
+def test_conv3d_stats_fused(case):
+    """dca_conv3d_x3_forward_stats: the same y as the plain bf16x3 launch (bitwise) and BatchNorm batch statistics of y that
+    match a float64 reference -- also when |mean| >> std, given a shift near the mean (the running mean in the model)"""
+    _, ops = _mods()
+    cin, cout, dims, N = case
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn((N, cin) + dims, generator=g) + 3.0      # non-zero mean input -> non-zero mean output
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.1 + 0.02
+    xg, wg = x.to(DEV), w.to(DEV)
+    y_ref = ops._conv_sliced(xg, None, wg, cin, cout, 27, 0, 0, 3, 1, False)
+    yd = y_ref.double()
+    mean_ref = yd.mean(dim=(0, 2, 3, 4))
+    var_ref = yd.var(dim=(0, 2, 3, 4), unbiased=False)
+    for shift in (torch.zeros(cout), mean_ref.float().cpu() * 0.97):
+        y, part = ops._Conv3dStats.apply(xg, wg, shift.to(DEV))
+        assert torch.equal(y, y_ref)
+        nchunk = (part.numel() - cout) // (2 * cout)
+        p = part[:cout * nchunk * 2].view(cout, nchunk, 2).sum(1)
+        K = part[cout * nchunk * 2:]
+        cnt = float(N * dims[0] * dims[1] * dims[2])
+        m1 = p[:, 0] / cnt
+        mean = K + m1
+        var = p[:, 1] / cnt - m1 * m1
+        assert torch.allclose(K.float().cpu(), shift)
+        assert (mean - mean_ref).abs().max().item() <= 2e-6 * mean_ref.abs().max().item() + 1e-6
+        tol = 2e-5 if shift.abs().max() == 0 else 2e-6          # unshifted fp32 partial sums lose digits to the mean
+        assert ((var - var_ref).abs() / var_ref).max().item() <= tol, ((var - var_ref).abs() / var_ref).max().item()
+    # bitwise reproducible
+    y2, part2 = ops._Conv3dStats.apply(xg, wg, shift.to(DEV))
+    assert torch.equal(part, part2)
+
+
+def test_convbn3d_training_uses_fused_statistics(monkeypatch):
+    """ops.convbn3d in training mode: statistics from the conv epilogue vs the separate pass -- same outputs, running
+    statistics and gradients to fp32 rounding"""
+    _, ops = _mods()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 32, 6, 12, 36, generator=g).to(DEV)
+    gy = torch.randn(2, 32, 6, 12, 36, generator=g).to(DEV)
+    res = {}
+    for fuse in (True, False):
+        monkeypatch.setattr(ops, "BN_FUSE", fuse)
+        torch.manual_seed(0)
+        conv = torch.nn.Conv3d(32, 32, 3, 1, 1, bias=False).to(DEV)
+        bn = torch.nn.BatchNorm3d(32).to(DEV)
+        with torch.no_grad():
+            bn.running_mean.normal_(0, 0.1); bn.weight.uniform_(0.5, 1.5); bn.bias.normal_()
+        xg = x.clone().requires_grad_()
+        z = ops.convbn3d(xg, conv, bn, slope=0.0)
+        gx, gw, gg = torch.autograd.grad((z * gy).sum(), [xg, conv.weight, bn.weight])
+        res[fuse] = (z, bn.running_mean.clone(), bn.running_var.clone(), gx, gw, gg, int(bn.num_batches_tracked))
+    for a, b, name in zip(res[True][:6], res[False][:6], ("z", "running_mean", "running_var", "gx", "gw", "ggamma")):
+        close(a, b.cpu(), 2e-5, name)
+    assert res[True][6] == res[False][6] == 1
+
+
 def test_conv3d_bf16x3_random_shapes(monkeypatch):
     """randomised shapes (tiny dims, channel counts off the 16/32 grid, W on and off the aligned path, batches) through
     the bf16x3 forward / backward-data / weight-gradient kernels against fp64 (tools/x3_stress.py runs 60 of these)"""
@@ -781,13 +848,18 @@ def test_graph_replay_matches_eager():
 
 
 def test_training_step_is_bitwise_reproducible():
-    """idempotence: forward + backward twice on the same inputs give bit-identical outputs and gradients (no float
-    atomics anywhere on the path; all cross-workgroup sums are order-fixed)"""
+    """idempotence: forward + backward twice on the same inputs AND the same module state give bit-identical outputs and
+    gradients (no float atomics anywhere on the path; all cross-workgroup sums are order-fixed).  The BatchNorm buffers are
+    part of that state: the convolution kernels that emit the batch statistics centre their sums on the running mean, so
+    a changed running mean changes the last bits of the batch statistics."""
+    import copy
     from dcanet_amd.models.gwcnet_dca_g import GwcNet
     m = load_seeded(GwcNet(32, use_concat_volume=True)).to(DEV).train()
+    state = copy.deepcopy(m.state_dict())
     fL, fR = gpu(seeded_tensor("hot.fL", (2, 332, 16, 32)), True), gpu(seeded_tensor("hot.fR", (2, 332, 16, 32)), True)
     runs = []
     for _ in range(2):
+        m.load_state_dict(state)
         r = m.hot_path(fL[:, :320], fR[:, :320], fL[:, 320:], fR[:, 320:])
         loss = r["pred4_q"].sum() + r["pred_dca3"].mean() + r["pred1"].square().sum()
         gr = torch.autograd.grad(loss, [fL, fR, m.dres0[0][0].weight, m.cva2.cost_agg.conv3[0].weight,
