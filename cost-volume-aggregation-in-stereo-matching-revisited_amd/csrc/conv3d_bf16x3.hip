@@ -422,8 +422,8 @@ __global__ __launch_bounds__(512) void conv3_bf16x3_kernel(X3Args a) {
         const float rs = row16_sum(st_s[r]), rq2 = row16_sum(st_q[r]);
         if ((lane & 15) == 0) {
           float* slot = stat_lds + wv * 128 + ((lane >> 4) * 16 + r) * 2;
-          slot[0] += rs;      // wave-private slot, one writer lane per slot
-          slot[1] += rq2;
+          atomicAdd(slot, rs);          // ds_add_f32 without return: no LDS round trip (still one writer per slot)      // wave-private slot, one writer lane per slot
+          atomicAdd(slot + 1, rq2);
         }
       }
     }

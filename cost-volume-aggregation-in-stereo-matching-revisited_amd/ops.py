@@ -356,9 +356,19 @@ def _out_dims(dims, ksize, stride, transposed):
 
 
 def _conv_sliced(x, x2, w_src, A, B, K, src_ab, flip, ksize, stride, transposed, scale=None, shift=None, slope=1.0,
-                 res_pre=None, res_post=None):
+                 res_pre=None, res_post=None, stat_shift=None):
     """y = conv(x [, x2]) with A contraction channels and B output channels, as ceil(B / slice) launches that each
-    write their channel slice of y (w_src is the PyTorch weight; src_ab / flip as in dca_conv3d_prep_weight)."""
+    write their channel slice of y (w_src is the PyTorch weight; src_ab / flip as in dca_conv3d_prep_weight).
+    stat_shift (B floats; no epilogue then): returns (y, part) where part holds the BatchNorm batch-statistics partial
+    sums of y emitted by the convolution kernel itself (layout of dca_bn_stats, shift K_c = stat_shift[c]), or
+    (y, None) when the kernel serving this shape has no such form."""
+    y, part = _conv_sliced_impl(x, x2, w_src, A, B, K, src_ab, flip, ksize, stride, transposed, scale, shift, slope,
+                                res_pre, res_post, stat_shift)
+    return y if stat_shift is None else (y, part)
+
+
+def _conv_sliced_impl(x, x2, w_src, A, B, K, src_ab, flip, ksize, stride, transposed, scale, shift, slope, res_pre,
+                      res_post, stat_shift):
     N = x.shape[0]
     Di, Hi, Wi = x.shape[2:]
     Do, Ho, Wo = _out_dims((Di, Hi, Wi), ksize, stride, transposed)
@@ -374,10 +384,16 @@ def _conv_sliced(x, x2, w_src, A, B, K, src_ab, flip, ksize, stride, transposed,
             return w3
         wx = _memo(("x3prep", A, B, int(src_ab), int(flip)), (w_src,), build_x3,
                    (1, A, B, 0, 0, 27, int(src_ab), int(flip), B, 0))
+        if stat_shift is not None:
+            nchunk = lib.dca_conv3d_x3_stats_chunks(N, B, Di, Hi, Wi)
+            part = torch.empty((B * nchunk * 2 + B,), device=x.device, dtype=torch.float64)
+            _chk(lib.dca_conv3d_x3_forward_stats(_ptr(x), _ptr(wx), _ptr(y), _ptr(stat_shift), _ptr(part), N, A, B, Di, Hi,
+                                                 Wi, _stream()), "dca_conv3d_x3_forward_stats")
+            return y, part
         _chk(lib.dca_conv3d_x3_forward(_ptr(x), _ptr(wx), _ptr(y), _ptr(scale), _ptr(shift), _ptr(res_pre),
                                        _ptr(res_post), float(slope), N, A, B, Di, Hi, Wi, _stream()),
              "dca_conv3d_x3_forward")
-        return y
+        return y, None
     if _dx3_eligible(x, x2, ksize, stride, transposed, A, B):
         def build_dx3():
             w3 = torch.empty((lib.dca_conv3d_x3_weight_bytes(A, B) // 2,), device=x.device, dtype=torch.int16)
@@ -386,13 +402,23 @@ def _conv_sliced(x, x2, w_src, A, B, K, src_ab, flip, ksize, stride, transposed,
             return w3
         wx = _memo(("x3prep", A, B, int(src_ab), int(flip)), (w_src,), build_dx3,
                    (1, A, B, 0, 0, 27, int(src_ab), int(flip), B, 0))
+        if stat_shift is not None:
+            nchunk = lib.dca_deconv3d_x3_stats_chunks(N, Di, Hi, Wi)
+            part = torch.empty((B * nchunk * 2 + B,), device=x.device, dtype=torch.float64)
+            _chk(lib.dca_deconv3d_x3_forward_stats(_ptr(x), _ptr(wx), _ptr(y), _ptr(stat_shift), _ptr(part), N, A, B, Di,
+                                                   Hi, Wi, _stream()), "dca_deconv3d_x3_forward_stats")
+            return y, part
         _chk(lib.dca_deconv3d_x3_forward(_ptr(x), _ptr(wx), _ptr(y), _ptr(scale), _ptr(shift), _ptr(res_pre),
                                          _ptr(res_post), float(slope), N, A, B, Di, Hi, Wi, _stream()),
              "dca_deconv3d_x3_forward")
-        return y
+        return y, None
     if _c1x3_eligible(x, x2, ksize, A, C1, y):
         S = Do * Ho * Wo
         C2 = 0 if x2 is None else x2.shape[1]
+        part = None
+        if stat_shift is not None:
+            nchunk = lib.dca_conv1_x3_stats_chunks(N, S)
+            part = torch.empty((B * nchunk * 2 + B,), device=x.device, dtype=torch.float64)
         for b0 in range(0, B, 32):
             bn = min(32, B - b0)
 
@@ -403,17 +429,21 @@ def _conv_sliced(x, x2, w_src, A, B, K, src_ab, flip, ksize, stride, transposed,
                 return wf
             wf = _memo(("c1x3prep", A, B, int(src_ab), b0, bn), (w_src,), build_c1,
                        (2, A, bn, 0, 0, 1, int(src_ab), 0, B, b0))
-            _chk(lib.dca_conv1_x3_forward(_ptr(x), _ptr(x2), _ptr(wf), _ptr(y), _ptr(scale), _ptr(shift), _ptr(res_pre),
-                                          _ptr(res_post), float(slope), N, C1, C2, bn, B, b0, S, _stream()),
-                 "dca_conv1_x3_forward")
-        return y
+            if part is not None:
+                _chk(lib.dca_conv1_x3_forward_stats(_ptr(x), _ptr(x2), _ptr(wf), _ptr(y), _ptr(stat_shift), _ptr(part), N,
+                                                    C1, C2, bn, B, b0, S, _stream()), "dca_conv1_x3_forward_stats")
+            else:
+                _chk(lib.dca_conv1_x3_forward(_ptr(x), _ptr(x2), _ptr(wf), _ptr(y), _ptr(scale), _ptr(shift),
+                                              _ptr(res_pre), _ptr(res_post), float(slope), N, C1, C2, bn, B, b0, S,
+                                              _stream()), "dca_conv1_x3_forward")
+        return y, part
     for b0 in range(0, B, width):
         bn = min(width, B - b0)
         wt, Apad = _prep_weight(w_src, A, B, K, src_ab, flip, ksize, stride, transposed, b0, bn)
         _chk(lib.dca_conv3d_forward(_ptr(x), _ptr(x2), _ptr(wt), _ptr(y), _ptr(scale), _ptr(shift), _ptr(res_pre),
                                     _ptr(res_post), float(slope), N, A, C1, bn, Apad, B, b0, Di, Hi, Wi, Do, Ho, Wo,
                                     ksize, stride, int(transposed), _stream()), "dca_conv3d_forward")
-    return y
+    return y, None
 
 
 def conv3d_prepared(x, wt, A, Apad, B, ksize, stride, transposed):
@@ -429,7 +459,7 @@ def conv3d_prepared(x, wt, A, Apad, B, ksize, stride, transposed):
 
 
 def _conv_forward_impl(x, x2, weight, stride, transposed, scale=None, shift=None, slope=1.0, res_pre=None,
-                       res_post=None):
+                       res_post=None, stat_shift=None):
     ksize = weight.shape[2]
     K = ksize ** 3
     if transposed:
@@ -440,7 +470,7 @@ def _conv_forward_impl(x, x2, weight, stride, transposed, scale=None, shift=None
         src_ab = 0
     assert x.shape[1] + (x2.shape[1] if x2 is not None else 0) == Cin, "conv3d: channel mismatch"
     return _conv_sliced(x, x2, weight, Cin, Cout, K, src_ab, 0, ksize, stride, transposed, scale, shift, slope,
-                        res_pre, res_post)
+                        res_pre, res_post, stat_shift)
 
 
 def _wgrad(x, dy, dw_view_ptr_tensor, dst_offset, Cx, Cy, ksize, stride, s_cy, s_cx):
@@ -503,17 +533,26 @@ class _Conv3d(torch.autograd.Function):
     Optional second input x2 = implicit channel concat for the 1x1x1 `fuse` conv."""
 
     @staticmethod
-    def forward(ctx, x, x2, weight, stride, transposed):
+    def forward(ctx, x, x2, weight, stride, transposed, stat_shift=None):
+        """stat_shift (Cout floats, e.g. a BatchNorm running mean): returns (y, part) -- part = the BatchNorm
+        batch-statistics partial sums of y from the convolution kernel's own epilogue (not differentiable), or None
+        where the kernel serving this shape cannot produce them"""
         x, weight = _req(x, "conv3d"), _req(weight, "conv3d.weight")
         x2 = _opt(x2, "conv3d.x2")
-        with torch.cuda.device_of(x):
-            y = _conv_forward_impl(x, x2, weight, stride, transposed)
         ctx.save_for_backward(x, x2, weight)
         ctx.meta = (stride, transposed)
-        return y
+        with torch.cuda.device_of(x):
+            if stat_shift is None:
+                return _conv_forward_impl(x, x2, weight, stride, transposed)
+            y, part = _conv_forward_impl(x, x2, weight, stride, transposed,
+                                         stat_shift=_req(stat_shift.detach(), "conv3d.stat_shift"))
+        if part is None:
+            part = torch.empty((0,), device=x.device, dtype=torch.float64)
+        ctx.mark_non_differentiable(part)
+        return y, part
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dpart=None):
         x, x2, weight = ctx.saved_tensors
         stride, transposed = ctx.meta
         dy = _req(dy, "conv3d.backward")
@@ -558,49 +597,16 @@ class _Conv3d(torch.autograd.Function):
                     _wgrad(x, dy, gw, 0, C1, Cout, 1, 1, Cin, 1)
                     if x2 is not None:
                         _wgrad(x2, dy, gw, C1, Cin - C1, Cout, 1, 1, Cin, 1)
-        return gx, gx2, gw, None, None
+        return gx, gx2, gw, None, None, None
 
 
-class _Conv3dStats(torch.autograd.Function):
-    """Conv3d(k=3, s=1, p=1, bias=False) on the bf16x3 kernel, which also emits the BatchNorm batch statistics of its
-    output (dca_conv3d_x3_forward_stats): returns (y, part); `shift` = per-channel shift of the sums (the running mean)."""
-
-    @staticmethod
-    def forward(ctx, x, weight, shift):
-        x, weight = _req(x, "conv3d"), _req(weight, "conv3d.weight")
-        N, Cin, D, H, W = x.shape
-        Cout = weight.shape[0]
-        lib = _L()
-        with torch.cuda.device_of(x):
-            def build_x3():
-                w3 = torch.empty((lib.dca_conv3d_x3_weight_bytes(Cin, Cout) // 2,), device=x.device, dtype=torch.int16)
-                _chk(lib.dca_conv3d_x3_prep_weight(_ptr(weight), _ptr(w3), Cin, Cout, 0, 0, _stream()),
-                     "dca_conv3d_x3_prep_weight")
-                return w3
-            wx = _memo(("x3prep", Cin, Cout, 0, 0), (weight,), build_x3, (1, Cin, Cout, 0, 0, 27, 0, 0, Cout, 0))
-            y = torch.empty((N, Cout, D, H, W), device=x.device, dtype=torch.float32)
-            nchunk = lib.dca_conv3d_x3_stats_chunks(N, Cout, D, H, W)
-            part = torch.empty((Cout * nchunk * 2 + Cout,), device=x.device, dtype=torch.float64)
-            shift = _req(shift.detach(), "conv3d.stat_shift")
-            _chk(lib.dca_conv3d_x3_forward_stats(_ptr(x), _ptr(wx), _ptr(y), _ptr(shift), _ptr(part), N, Cin, Cout, D, H, W,
-                                                 _stream()), "dca_conv3d_x3_forward_stats")
-        ctx.save_for_backward(x, weight)
-        ctx.mark_non_differentiable(part)
-        return y, part
+class _Conv3dStats:
+    """Conv3d(k=3, s=1, p=1, bias=False) whose kernel also emits the BatchNorm batch statistics of its output:
+    apply(x, weight, shift) -> (y, part).  (`_Conv3d` with a stat_shift; kept as the test entry point.)"""
 
     @staticmethod
-    def backward(ctx, dy, _dpart):
-        x, weight = ctx.saved_tensors
-        dy = _req(dy, "conv3d.backward")
-        Cout, Cin = weight.shape[0], weight.shape[1]
-        gx = gw = None
-        with torch.cuda.device_of(x):
-            if ctx.needs_input_grad[0]:
-                gx = _conv_sliced(dy, None, weight, Cout, Cin, 27, 1, 1, 3, 1, False)
-            if ctx.needs_input_grad[1]:
-                gw = torch.empty_like(weight)
-                _wgrad(x, dy, gw, 0, Cin, Cout, 3, 1, Cin * 27, 27)
-        return gx, gw, None
+    def apply(x, weight, shift):
+        return _Conv3d.apply(x, None, weight, 1, False, shift)
 
 
 def conv3d(x, weight, stride=1, transposed=False, x2=None):
@@ -901,13 +907,12 @@ def convbn3d(x, conv, bn, slope=1.0, res_pre=None, res_post=None, x2=None):
         C = bn.num_features
         return conv3d_fused_inference(xx, conv.weight, stride, transposed, stats[2 * C:3 * C], stats[3 * C:], slope,
                                       res_pre, res_post, x2)
-    if (BN_FUSE and bn.training and bn.running_mean is not None and not transposed and stride == 1 and x2 is None
-            and conv.kernel_size[0] == 3 and conv.weight.shape[0] > 1 and _lp_dtype() is None and x.is_cuda
-            and x.dtype == torch.float32 and x.is_contiguous()
-            and _x3_eligible(x, None, 3, 1, False, conv.weight.shape[1], conv.weight.shape[0])):
-        # the convolution kernel emits the batch statistics of its own output: no separate pass over y
-        y, part = _Conv3dStats.apply(x, conv.weight, bn.running_mean)
-        return bn_act(y, bn, slope, res_pre, res_post, part)
+    if (BN_FUSE and bn.training and bn.running_mean is not None and conv.weight.shape[0 if not transposed else 1] > 1
+            and _lp_dtype() is None):
+        # the convolution kernel emits the batch statistics of its own output where it has such a form (the bf16x3 family):
+        # no separate pass over y
+        y, part = _Conv3d.apply(x, x2, conv.weight, int(stride), bool(transposed), bn.running_mean)
+        return bn_act(y, bn, slope, res_pre, res_post, part if part.numel() else None)
     y = conv3d(x, conv.weight, stride, transposed, x2)
     return bn_act(y, bn, slope, res_pre, res_post)
 

@@ -23,7 +23,7 @@ extern "C" {
 
 /* Bumped whenever an argument list below changes; the ctypes loader (_lib.py) refuses a library built from another
  * version of this header. */
-#define DCA_ABI_VERSION 7
+#define DCA_ABI_VERSION 8
 int dca_abi_version(void);
 
 /* storage types of the reduced-precision inference path (0 = fp32) */
@@ -163,6 +163,15 @@ int dca_deconv3d_x3_forward(const float* x, const void* wx, float* y, const floa
 long dca_conv3d_x3_stats_chunks(int N, int Cout, int D, int H, int W);
 int dca_conv3d_x3_forward_stats(const float* x, const void* wx, float* y, const float* stat_shift, double* stat_part,
                                 int N, int Cin, int Cout, int D, int H, int W, hipStream_t stream);
+/* The same for the 1x1x1 convolutions (conv1_x3.hip; part covers all CoutTotal channels, every channel slice of a sliced
+ * convolution fills its own rows; stat_shift has CoutTotal entries) and the transposed convolution (deconv3d_x3.hip). */
+long dca_conv1_x3_stats_chunks(int N, long S);
+int dca_conv1_x3_forward_stats(const float* x, const float* x2, const void* wfrag, float* y, const float* stat_shift,
+                               double* stat_part, int N, int C1, int C2, int Cout, int CoutTotal, int co_off, long S,
+                               hipStream_t stream);
+long dca_deconv3d_x3_stats_chunks(int N, int Di, int Hi, int Wi);
+int dca_deconv3d_x3_forward_stats(const float* x, const void* wx, float* y, const float* stat_shift, double* stat_part,
+                                  int N, int Cin, int Cout, int Di, int Hi, int Wi, hipStream_t stream);
 
 /* Weight gradient of the 3x3x3 / stride-1 / pad-1 convolution on the bf16 matrix pipe with the same exact three-way
  * bf16 split (conv3d_wgrad_bf16x3.hip); replaces dca_conv3d_wgrad for ksize 3, stride 1 (autograd's dW of the nn.Conv3d

@@ -269,45 +269,56 @@ def test_deconv3d_bf16x3(case, monkeypatch):
 
 
 STATS_CASES = [
-    # cin, cout, dims, N
-    (32, 32, (5, 10, 36), 2),
-    (40, 27, (4, 6, 20), 1),
-    (16, 64, (3, 9, 17), 2),      # two channel blocks, single-voxel staging path
-    (32, 32, (9, 17, 33), 1),
-    (32, 32, (1, 2, 4), 1),       # fewer tiles than workgroups
+    # kind, cin, cout, dims, N      (kind: c3 = 3x3x3 stride 1, c1 = 1x1x1, c1x2 = 1x1x1 over two inputs, dc = transposed)
+    ("c3", 32, 32, (5, 10, 36), 2),
+    ("c3", 40, 27, (4, 6, 20), 1),
+    ("c3", 16, 64, (3, 9, 17), 2),      # two channel blocks, single-voxel staging path
+    ("c3", 32, 32, (9, 17, 33), 1),
+    ("c3", 32, 32, (1, 2, 4), 1),       # fewer tiles than workgroups
+    ("c1", 32, 32, (5, 10, 36), 2),
+    ("c1", 64, 64, (3, 7, 12), 1),      # two channel slices
+    ("c1", 32, 27, (2, 3, 4), 1),
+    ("c1x2", 64, 32, (4, 6, 20), 2),
+    ("dc", 64, 32, (3, 5, 12), 2),
+    ("dc", 40, 27, (2, 9, 20), 1),
 ]
 
 
 @pytest.mark.parametrize("case", STATS_CASES, ids=[str(c) for c in STATS_CASES])
 def test_conv3d_stats_fused(case):
-    """dca_conv3d_x3_forward_stats: the same y as the plain bf16x3 launch (bitwise) and BatchNorm batch statistics of y that
-    match a float64 reference -- also when |mean| >> std, given a shift near the mean (the running mean in the model)"""
+    """the *_forward_stats kernels: the same y as the plain launch (bitwise) and BatchNorm batch statistics of y that match
+    a float64 reference -- also when |mean| >> std, given a shift near the mean (the running mean in the model)"""
     _, ops = _mods()
-    cin, cout, dims, N = case
+    kind, cin, cout, dims, N = case
     g = torch.Generator().manual_seed(11)
     x = torch.randn((N, cin) + dims, generator=g) + 3.0      # non-zero mean input -> non-zero mean output
-    w = torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.1 + 0.02
+    k = 1 if kind.startswith("c1") else 3
+    wshape = (cin, cout, 3, 3, 3) if kind == "dc" else (cout, cin, k, k, k)
+    w = torch.randn(wshape, generator=g) * 0.1 + 0.02
     xg, wg = x.to(DEV), w.to(DEV)
-    y_ref = ops._conv_sliced(xg, None, wg, cin, cout, 27, 0, 0, 3, 1, False)
+    x1, x2 = (xg[:, :32].contiguous(), xg[:, 32:].contiguous()) if kind == "c1x2" else (xg, None)
+    stride, transposed = (2, True) if kind == "dc" else (1, False)
+    y_ref = ops._Conv3d.apply(x1, x2, wg, stride, transposed)
     yd = y_ref.double()
     mean_ref = yd.mean(dim=(0, 2, 3, 4))
     var_ref = yd.var(dim=(0, 2, 3, 4), unbiased=False)
+    cnt = float(y_ref.numel() // cout)
     for shift in (torch.zeros(cout), mean_ref.float().cpu() * 0.97):
-        y, part = ops._Conv3dStats.apply(xg, wg, shift.to(DEV))
+        y, part = ops._Conv3d.apply(x1, x2, wg, stride, transposed, shift.to(DEV))
+        assert part.numel() > 0, "this shape should be served by a statistics-emitting kernel"
         assert torch.equal(y, y_ref)
         nchunk = (part.numel() - cout) // (2 * cout)
         p = part[:cout * nchunk * 2].view(cout, nchunk, 2).sum(1)
         K = part[cout * nchunk * 2:]
-        cnt = float(N * dims[0] * dims[1] * dims[2])
         m1 = p[:, 0] / cnt
         mean = K + m1
         var = p[:, 1] / cnt - m1 * m1
         assert torch.allclose(K.float().cpu(), shift)
         assert (mean - mean_ref).abs().max().item() <= 2e-6 * mean_ref.abs().max().item() + 1e-6
-        tol = 2e-5 if shift.abs().max() == 0 else 2e-6          # unshifted fp32 partial sums lose digits to the mean
+        tol = 5e-5 if shift.abs().max() == 0 else 2e-6          # unshifted fp32 partial sums lose digits to the mean
         assert ((var - var_ref).abs() / var_ref).max().item() <= tol, ((var - var_ref).abs() / var_ref).max().item()
     # bitwise reproducible
-    y2, part2 = ops._Conv3dStats.apply(xg, wg, shift.to(DEV))
+    y2, part2 = ops._Conv3d.apply(x1, x2, wg, stride, transposed, shift.to(DEV))
     assert torch.equal(part, part2)
 
 
