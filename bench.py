@@ -168,12 +168,28 @@ def kernel_roofline(device, dtype="f32"):
                           "wgrad3_bf16x3", PEAK_BF16_MFMA_TFLOPS / 6.0, run_wgrad(True)))
         cases.append(("wgrad3_kernel<S1> (+reduce) (dW of 3x3x3 32->32 @1/4 res, fp32 MFMA)", "wgrad3",
                       PEAK_FP32_MFMA_TFLOPS, run_wgrad(False)))
+        # the transposed convolution of the cva blocks (64 -> 32, 1/8 -> 1/4 res), same 6-product split: its own FLOP count
+        if ops.CONV_X3 and ops.DECONV_X3:
+            xc = torch.randn(1, 64, d // 2, h // 2, w // 2, device=device)
+            wdc = torch.randn(64, 32, 3, 3, 3, device=device) * 0.05
+            cases.append(("deconv3_bf16x3_kernel (ConvTranspose3d 3x3x3 s2 64->32, 1/8 -> 1/4 res; 6 bf16 MFMA products per "
+                          "fp32 product, half-group schedule)", "deconv3_bf16x3", PEAK_BF16_MFMA_TFLOPS / 6.0,
+                          lambda: ops._conv_sliced(xc, None, wdc, 64, 32, 27, 1, 0, 3, 2, True),
+                          2.0 * 27 * 64 * 32 * (d // 2) * (h // 2) * (w // 2)))
+        # the 1x1x1 convolutions are bandwidth bound: 4*(Cin + Cout)*V4 algorithmic bytes per launch
+        if ops.CONV_X3:
+            w1 = torch.randn(32, 32, 1, 1, 1, device=device) * 0.1
+            cases.append(("conv1_x3_kernel<2,0> (1x1x1 32->32 @1/4 res; fp32-grade on the bf16 pipe, LDS-free)", "conv1_x3",
+                          None, lambda: ops._conv_sliced(x, None, w1, 32, 32, 1, 0, 0, 1, 1, False),
+                          4.0 * 64 * d * h * w))
         # the cost-volume builder itself is bandwidth bound: 4*(2*320*hw + 40*V4) algorithmic bytes per launch
         fl, fr = torch.randn(1, 320, h, w, device=device), torch.randn(1, 320, h, w, device=device)
         gwc_bytes = 4.0 * (2 * 320 * h * w + 40 * d * h * w)
-        cases.append(("gwc_fused_kernel<8> (build_gwc_volume, 40 groups x %d disparities @1/4 res, fp32 volume)" % d, None,
-                      None, lambda: ops.cost_volume(fl, fr, d, 40)))
-        for name, key, peak, fn in cases:
+        cases.append(("gwc_fused_kernel<8> (build_gwc_volume, 40 groups x %d disparities @1/4 res, fp32 volume)" % d,
+                      "gwc_fused", None, lambda: ops.cost_volume(fl, fr, d, 40), gwc_bytes))
+        for case in cases:
+            name, key, peak, fn = case[:4]
+            work = case[4] if len(case) > 4 else None   # FLOP (mfma entries) or bytes (hbm entries) when not the default
             for _ in range(2):
                 fn()
             torch.cuda.synchronize()
@@ -186,21 +202,22 @@ def kernel_roofline(device, dtype="f32"):
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / reps
             if peak is None:   # HBM-bound entry
-                gbs = gwc_bytes / (ms * 1e-3) / 1e9
+                gbs = work / (ms * 1e-3) / 1e9
                 out[name] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                              "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "ms_per_launch": round(ms, 4),
-                             "algorithmic_bytes": gwc_bytes, "pmc_key": None}
+                             "algorithmic_bytes": work, "pmc_key": key}
                 continue
-            tf = flops / (ms * 1e-3) / 1e12
+            fl_launch = flops if work is None else work
+            tf = fl_launch / (ms * 1e-3) / 1e12
             out[name] = {"bound": "mfma", "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(tf / peak, 4), "traffic": None, "ms_per_launch": round(ms, 4),
-                         "flop_per_launch": flops, "pmc_key": key}
+                         "flop_per_launch": fl_launch, "pmc_key": key}
             if key == "conv3_lp":
                 lp_bytes = 2.0 * 2 * 32 * d * h * w
                 out[name]["algorithmic_bytes"] = lp_bytes
                 out[name]["hbm_view"] = {"achieved": round(lp_bytes / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
                                          "unit": "GB/s", "frac": round(lp_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
-            if key in ("conv3_bf16x3", "wgrad3_bf16x3"):
+            if key in ("conv3_bf16x3", "wgrad3_bf16x3", "deconv3_bf16x3"):
                 out[name]["peak_note"] = "dense bf16 MFMA peak (2500) / 6 products per fp32 product"
                 out[name]["executed_bf16"] = {"achieved": round(6 * tf, 1), "peak": PEAK_BF16_MFMA_TFLOPS,
                                               "unit": "TFLOP/s", "frac": round(6 * tf / PEAK_BF16_MFMA_TFLOPS, 4)}

@@ -22,12 +22,14 @@ sys.path.insert(0, ROOT)
 
 V4 = 48 * 136 * 240
 KEYS = {   # substring of the kernel name -> (key, algorithmic bytes per launch)
-    "conv3_bf16x3_kernel": ("conv3_bf16x3", 2 * 32 * V4 * 4 + 27 * 32 * 32 * 4),
+    "::conv3_bf16x3_kernel": ("conv3_bf16x3", 2 * 32 * V4 * 4 + 27 * 32 * 32 * 4),
     "wgrad3_bf16x3_kernel": ("wgrad3_bf16x3", 2 * 32 * V4 * 4 + 27 * 32 * 32 * 4),
     "conv3_mfma_kernel<1, 1, 8, 4, 8, 16, true": ("conv3_mfma", 2 * 32 * V4 * 4 + 27 * 32 * 32 * 4),
     "wgrad3_kernel<1, 16>": ("wgrad3", 2 * 32 * V4 * 4 + 27 * 32 * 32 * 4),
     "conv3_lp_kernelIDF16bLb0ELb0ELb1ELi1": ("conv3_lp", 2 * 32 * V4 * 2 + 27 * 32 * 32 * 2),
     "gwc_fused_kernel<8, float>": ("gwc_fused", 4 * (2 * 320 * 136 * 240 + 40 * V4)),
+    "::deconv3_bf16x3_kernel": ("deconv3_bf16x3", 4 * (64 * V4 // 8 + 32 * V4) + 27 * 64 * 32 * 4),
+    "conv1_x3_kernel<2, 0": ("conv1_x3", 4 * 64 * V4),
 }
 
 
