@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(HERE, "libdca_hip.so")
 
 _p, _i, _l, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double
 
-ABI_VERSION = 8   # == DCA_ABI_VERSION of include/dca_hip.h
+ABI_VERSION = 9   # == DCA_ABI_VERSION of include/dca_hip.h
 
 # name -> (restype, argtypes); mirrors include/dca_hip.h one to one
 SIGNATURES = {
@@ -32,11 +32,12 @@ SIGNATURES = {
     "dca_conv3d_x3_prep_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "dca_conv3d_x3_forward": (_i, [_p] * 7 + [_f] + [_i] * 6 + [_p]),
     "dca_conv3d_x3_stats_chunks": (_l, [_i] * 5),
-    "dca_conv3d_x3_forward_stats": (_i, [_p] * 5 + [_i] * 6 + [_p]),
+    "dca_conv3d_x3_forward_stats": (_i, [_p] * 4 + [_i] * 6 + [_p]),
+    "dca_bn_finalize_centered": (_i, [_p, _i, _p, _p, _p, _p, _f, _f, _p, _i, _p]),
     "dca_conv1_x3_stats_chunks": (_l, [_i, _l]),
-    "dca_conv1_x3_forward_stats": (_i, [_p] * 6 + [_i] * 6 + [_l, _p]),
+    "dca_conv1_x3_forward_stats": (_i, [_p] * 5 + [_i] * 6 + [_l, _p]),
     "dca_deconv3d_x3_stats_chunks": (_l, [_i] * 4),
-    "dca_deconv3d_x3_forward_stats": (_i, [_p] * 5 + [_i] * 6 + [_p]),
+    "dca_deconv3d_x3_forward_stats": (_i, [_p] * 4 + [_i] * 6 + [_p]),
     "dca_deconv3d_x3_forward": (_i, [_p] * 7 + [_f] + [_i] * 6 + [_p]),
     "dca_conv3d_wgrad_workspace": (_l, [_i] * 8),
     "dca_conv3d_wgrad_x3_workspace": (_l, [_i] * 6),

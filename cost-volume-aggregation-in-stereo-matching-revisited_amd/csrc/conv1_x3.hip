@@ -17,6 +17,7 @@
 // a term is the 8 channels of its own voxel 4r + t -- four dwords, each the packed pair (channel 2j, 2j+1) -- built in
 // registers.  Per output channel the four tiles give the lane's four voxels again: one 16-byte store.
 #include "dca_common.h"
+#include "bn_fused_stats.h"
 #include "../../include/dca_hip.h"
 
 typedef __bf16 cx_bf16x8 __attribute__((ext_vector_type(8)));
@@ -35,18 +36,8 @@ struct C1XArgs {
   float slope;
   int N, C1, C2, Cout, CoutTotal, co_off;
   long S;
-  const float* stat_shift;   // STATS: per-channel shift K_c (CoutTotal floats)
-  double* stat_part;         // STATS: part[(c*nchunk + i)*2 + {0,1}], c in [0, CoutTotal), nchunk = 2 * gridDim.x; K_c at the end
+  double* stat_part;         // STATS: one partial {K, n, s, q} per (channel of CoutTotal, workgroup): bn_fused_stats.h
 };
-
-// sum over the 16 lanes of a DPP row, result in every lane of the row
-__device__ __forceinline__ float cx_row16_sum(float x) {
-  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xF, 0xF, true));   // row_half_mirror
-  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xF, 0xF, true));   // row_mirror
-  return x;
-}
 
 __device__ __forceinline__ unsigned cx_pack2(float a, float b) {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -56,19 +47,18 @@ __device__ __forceinline__ unsigned cx_pack2(float a, float b) {
 }
 
 // NC1 / NC2: 16-channel chunks of the first / second input (C1 = 16 * NC1 exactly; S % 4 == 0, aligned bases).
-// STATS: the output feeds a training-mode BatchNorm; the kernel also emits the per-channel partial sums of (y - K_c) and
-// (y - K_c)^2 (layout of dca_bn_stats, one partial per workgroup and DPP-row parity; see conv3d_bf16x3.hip).
+// STATS: the output feeds a training-mode BatchNorm; the kernel also emits the per-(channel, workgroup) partial statistics
+// of bn_fused_stats.h.
 template <int NC1, int NC2, bool STATS>
 __global__ __launch_bounds__(256, 2) void conv1_x3_kernel(C1XArgs a) {
   constexpr int NCH = NC1 + NC2;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
   __shared__ float aff[64];
-  __shared__ float stat_lds[STATS ? 4 * 128 + 32 : 1];   // [wave][row][r][sum, sum of squares] + 32 shifts
+  __shared__ float stat_lds[STATS ? 4 * FS_WAVE_FLOATS : 1];
+  float* stat_w = stat_lds + (STATS ? wv * FS_WAVE_FLOATS : 0);
+  bool stat_first = true;
   if constexpr (STATS) {
-    for (int i = threadIdx.x; i < 4 * 128; i += 256) stat_lds[i] = 0.f;
-    if (threadIdx.x < 32) stat_lds[512 + threadIdx.x] = threadIdx.x < a.Cout ? a.stat_shift[a.co_off + threadIdx.x] : 0.f;
-    if (blockIdx.x == 0 && threadIdx.x < a.Cout)
-      a.stat_part[(long)a.CoutTotal * (2 * gridDim.x) * 2 + a.co_off + threadIdx.x] = (double)a.stat_shift[a.co_off + threadIdx.x];
+    for (int i = threadIdx.x; i < 4 * FS_WAVE_FLOATS; i += 256) stat_lds[i] = 0.f;
   }
   const bool has_aff = a.scale != nullptr, has_pre = a.res_pre != nullptr, has_post = a.res_post != nullptr;
   if (threadIdx.x < 64) {
@@ -84,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void conv1_x3_kernel(C1XArgs a) {
   __syncthreads();
 
   constexpr bool LANE_ACC = STATS && NCH <= 2;   // the 64-channel forms have no 32 registers to spare
-  float st_s[LANE_ACC ? 16 : 1], st_q[LANE_ACC ? 16 : 1];
+  float st_s[LANE_ACC ? 16 : 1], st_q[LANE_ACC ? 16 : 1], st_n = 0.f;
   if constexpr (LANE_ACC) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) st_s[r] = st_q[r] = 0.f;
@@ -170,47 +160,46 @@ __global__ __launch_bounds__(256, 2) void conv1_x3_kernel(C1XArgs a) {
         const u32x4 w_ = {__float_as_uint(o0), __float_as_uint(o1), __float_as_uint(o2), __float_as_uint(o3)};
         __builtin_amdgcn_raw_buffer_store_b128(w_, yr, ob + (int)(((r & 3) + 8 * (r >> 2)) * a.S * 4), 0, 0);
         if constexpr (STATS) {
-          const float k = stat_lds[512 + cl];
+          if (stat_first) {   // the wave's first group: the shift of (half, r) = what lane 0 of the half produced
+            const float kf = fs_half_first(o0, half);
+            if ((lane & 31) == 0) fs_slot(stat_w, half, r)[0] = kf;
+          }
+          const float k = fs_slot(stat_w, half, r)[0];
           const float d0 = inr ? o0 - k : 0.f, d1 = inr ? o1 - k : 0.f, d2 = inr ? o2 - k : 0.f, d3 = inr ? o3 - k : 0.f;
           const float ps = (d0 + d1) + (d2 + d3), pq = fmaf(d0, d0, d1 * d1) + fmaf(d2, d2, d3 * d3);
           if constexpr (LANE_ACC) {   // per-lane running sums, reduced over lanes and waves once at the end of the kernel
             st_s[r] += ps;
             st_q[r] += pq;
-          } else {                    // no registers to spare: reduce the 16-lane row now, one LDS add per (row, channel)
-            const float rs = cx_row16_sum(ps), rq2 = cx_row16_sum(pq);
-            if ((lane & 15) == 0) {
-              float* slot = stat_lds + wv * 128 + ((lane >> 4) * 16 + r) * 2;   // wave-private, one writer lane per slot
-              atomicAdd(slot, rs);          // ds_add_f32 without return: no LDS round trip
-              atomicAdd(slot + 1, rq2);
+          } else {                    // no registers to spare: reduce the wave half now, one LDS add per (half, channel)
+            const float rs = fs_half_sum(ps), rq2 = fs_half_sum(pq);
+            if ((lane & 31) == 0) {
+              atomicAdd(fs_slot(stat_w, half, r) + 1, rs);   // ds_add_f32 without return; wave-private, one writer lane
+              atomicAdd(fs_slot(stat_w, half, r) + 2, rq2);
             }
           }
         }
       }
     }
+    if constexpr (STATS) {
+      st_n += 4.f * (float)inr;
+      stat_first = false;
+    }
   }
   if constexpr (STATS) {
-    // lanes of a 16-lane row reduced by DPP, then the four waves summed in wave order: channel co_off + cu(r) + 4*(row >> 1),
-    // partial index blockIdx.x*2 + (row & 1)
     if constexpr (LANE_ACC) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float rs = cx_row16_sum(st_s[r]), rq2 = cx_row16_sum(st_q[r]);
-        if ((lane & 15) == 0) {
-          stat_lds[wv * 128 + ((lane >> 4) * 16 + r) * 2] = rs;
-          stat_lds[wv * 128 + ((lane >> 4) * 16 + r) * 2 + 1] = rq2;
+        const float rs = fs_half_sum(st_s[r]), rq2 = fs_half_sum(st_q[r]);
+        if ((lane & 31) == 0) {
+          fs_slot(stat_w, half, r)[1] = rs;
+          fs_slot(stat_w, half, r)[2] = rq2;
         }
       }
     }
+    const float rn = fs_half_sum(st_n);
+    if ((lane & 31) == 0) stat_w[96 + half] = rn;
     __syncthreads();
-    if (threadIdx.x < 128) {
-      const int i = threadIdx.x, pair = i & 1, r = (i >> 1) & 15, row = i >> 5;
-      const int cl = (r & 3) + 8 * (r >> 2) + 4 * (row >> 1);
-      float sum = 0.f;
-#pragma unroll
-      for (int w4 = 0; w4 < 4; ++w4) sum += stat_lds[w4 * 128 + i];
-      if (cl < a.Cout)
-        a.stat_part[((long)(a.co_off + cl) * (2 * gridDim.x) + blockIdx.x * 2 + (row & 1)) * 2 + pair] = (double)sum;
-    }
+    fs_flush(stat_lds, 4, threadIdx.x, a.co_off, a.co_off + a.Cout, a.stat_part, gridDim.x, blockIdx.x);
   }
 }
 
@@ -264,8 +253,8 @@ long c1x_blocks(int N, long S) {
 }
 
 int c1x_launch(const float* x, const float* x2, const void* wfrag, float* y, const float* scale, const float* shift,
-               const float* res_pre, const float* res_post, float slope, const float* stat_shift, double* stat_part, int N,
-               int C1, int C2, int Cout, int CoutTotal, int co_off, long S, hipStream_t stream) {
+               const float* res_pre, const float* res_post, float slope, double* stat_part, int N, int C1, int C2, int Cout,
+               int CoutTotal, int co_off, long S, hipStream_t stream) {
   DCA_REQUIRE(x && wfrag && y && N > 0 && Cout > 0 && Cout <= 32 && co_off >= 0 && co_off + Cout <= CoutTotal && S > 0);
   DCA_REQUIRE((x2 != nullptr) == (C2 > 0));
   DCA_REQUIRE((C1 == 32 && C2 == 0) || (C1 == 64 && C2 == 0) || (C1 == 32 && C2 == 32));
@@ -277,7 +266,7 @@ int c1x_launch(const float* x, const float* x2, const void* wfrag, float* y, con
   a.x = x; a.x2 = x2; a.wfrag = (const unsigned short*)wfrag; a.y = y; a.scale = scale; a.shift = shift;
   a.res_pre = res_pre; a.res_post = res_post; a.slope = slope;
   a.N = N; a.C1 = C1; a.C2 = C2; a.Cout = Cout; a.CoutTotal = CoutTotal; a.co_off = co_off; a.S = S;
-  a.stat_shift = stat_shift; a.stat_part = stat_part;
+  a.stat_part = stat_part;
   const dim3 grid((int)c1x_blocks(N, S));
   if (stat_part) {
     if (C2) hipLaunchKernelGGL((conv1_x3_kernel<2, 2, true>), grid, dim3(256), 0, stream, a);
@@ -296,23 +285,23 @@ int c1x_launch(const float* x, const float* x2, const void* wfrag, float* y, con
 extern "C" int dca_conv1_x3_forward(const float* x, const float* x2, const void* wfrag, float* y, const float* scale,
                                     const float* shift, const float* res_pre, const float* res_post, float slope, int N,
                                     int C1, int C2, int Cout, int CoutTotal, int co_off, long S, hipStream_t stream) {
-  return c1x_launch(x, x2, wfrag, y, scale, shift, res_pre, res_post, slope, nullptr, nullptr, N, C1, C2, Cout, CoutTotal,
-                    co_off, S, stream);
+  return c1x_launch(x, x2, wfrag, y, scale, shift, res_pre, res_post, slope, nullptr, N, C1, C2, Cout, CoutTotal, co_off, S,
+                    stream);
 }
 
-// nchunk of the statistics dca_conv1_x3_forward_stats produces (2 per workgroup of the launch it will make)
+// nchunk of the statistics dca_conv1_x3_forward_stats produces (one partial per workgroup of the launch it will make)
 extern "C" long dca_conv1_x3_stats_chunks(int N, long S) {
   if (N <= 0 || S <= 0) return 0;
-  return 2 * c1x_blocks(N, S);
+  return c1x_blocks(N, S);
 }
 
 // y = conv(x [, x2]) (no epilogue) on channels [co_off, co_off + Cout) plus their BatchNorm batch statistics: part
-// (CoutTotal*nchunk*2 + CoutTotal doubles, nchunk = dca_conv1_x3_stats_chunks(N, S); every channel slice of a sliced
-// convolution fills its own rows) in the layout of dca_bn_stats with K_c = stat_shift[c]
-extern "C" int dca_conv1_x3_forward_stats(const float* x, const float* x2, const void* wfrag, float* y,
-                                          const float* stat_shift, double* stat_part, int N, int C1, int C2, int Cout,
-                                          int CoutTotal, int co_off, long S, hipStream_t stream) {
-  DCA_REQUIRE(stat_shift && stat_part);
-  return c1x_launch(x, x2, wfrag, y, nullptr, nullptr, nullptr, nullptr, 1.f, stat_shift, stat_part, N, C1, C2, Cout,
-                    CoutTotal, co_off, S, stream);
+// (CoutTotal * nchunk * 4 doubles, nchunk = dca_conv1_x3_stats_chunks(N, S); every channel slice of a sliced convolution
+// fills its own channels) = one {K, n, sum (y - K), sum (y - K)^2} per (channel, workgroup), for dca_bn_finalize_centered
+extern "C" int dca_conv1_x3_forward_stats(const float* x, const float* x2, const void* wfrag, float* y, double* stat_part,
+                                          int N, int C1, int C2, int Cout, int CoutTotal, int co_off, long S,
+                                          hipStream_t stream) {
+  DCA_REQUIRE(stat_part);
+  return c1x_launch(x, x2, wfrag, y, nullptr, nullptr, nullptr, nullptr, 1.f, stat_part, N, C1, C2, Cout, CoutTotal,
+                    co_off, S, stream);
 }

@@ -22,6 +22,7 @@
 // channel chunk is three phases of 108 MFMAs per wave with one barrier each; the next slab / next halo tile are
 // fetched into registers (hardware-predicated buffer loads) while the current phase's MFMAs run.
 #include "dca_common.h"
+#include "bn_fused_stats.h"
 #include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -65,20 +66,10 @@ struct X3Args {
   int N, Cin, Cout, NCH;
   int D, H, W;
   int nTD, nTH, nTW;
-  const float* stat_shift;   // STATS: per-channel shift K_c (the BatchNorm running mean), Cout floats
-  double* stat_part;         // STATS: part[(c*nchunk + i)*2 + {0,1}] partial sums of (y - K_c), (y - K_c)^2; K_c at the end
+  double* stat_part;         // STATS: one partial {K, n, s, q} per (channel, workgroup): bn_fused_stats.h
 };
 
-constexpr int STAT_LDS = 8 * 4 * 16 * 2 * 4 + 128;   // [wave][16-lane row][r][sum, sum of squares] floats + 32 shifts
-
-// sum over the 16 lanes of a DPP row, result in every lane of the row
-__device__ __forceinline__ float row16_sum(float x) {
-  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xF, 0xF, true));   // row_half_mirror
-  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xF, 0xF, true));   // row_mirror
-  return x;
-}
+constexpr int STAT_LDS = 8 * FS_WAVE_FLOATS * 4;
 
 __device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l) {
   h = (__bf16)v;
@@ -88,11 +79,10 @@ __device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l)
   l = (__bf16)r2;
 }
 
-// STATS: the raw convolution output feeds a training-mode BatchNorm -- the kernel also produces the per-channel partial
-// sums of (y - K_c) and (y - K_c)^2 that dca_bn_finalize consumes (the layout of dca_bn_stats, nchunk = 2 * gridDim.x:
-// one partial per workgroup and row parity), so the 200 MB statistics pass over y disappears.  Per tile: 3 vector
-// instructions per output value, a 4-step DPP reduction over the 16 positions of a row, one ds_add_f32 per (row, channel)
-// into a wave-private LDS slot; fixed order, no atomics between waves: bitwise reproducible.
+// STATS: the raw convolution output feeds a training-mode BatchNorm -- the kernel also produces, per channel and workgroup,
+// the partial statistics {K, n, sum (y - K), sum (y - K)^2} that dca_bn_finalize_centered consumes (bn_fused_stats.h), so the
+// 200 MB statistics pass over y disappears.  Per tile: 3 vector instructions per output value, a DPP reduction over the 32
+// positions of a wave half, one ds_add_f32 per (half, channel) into a wave-private LDS slot.
 template <bool VEC, bool STATS>
 __global__ __launch_bounds__(512) void conv3_bf16x3_kernel(X3Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -110,30 +100,14 @@ __global__ __launch_bounds__(512) void conv3_bf16x3_kernel(X3Args a) {
   const int nx = gridDim.x >= 8 ? 8 : 1, xcd = blockIdx.x % nx;
   const int cnt = (gridDim.x - xcd + nx - 1) / nx;          // workgroups on this XCD
   const int t_begin = (int)(T * xcd / nx) + blockIdx.x / nx, t_end = (int)(T * (xcd + 1) / nx), t_step = cnt;
-  const int stat_nchunk = 2 * gridDim.x;
+  float* stat_w = stat_lds + wv * FS_WAVE_FLOATS;   // this wave's slots
+  bool stat_first = true;
   if constexpr (STATS) {
-    // this wave's 4 x 16 x 2 accumulators, and the shifts of this channel block
-    for (int i = lane; i < 128; i += 64) stat_lds[wv * 128 + i] = 0.f;
-    if (tid < 32) stat_lds[1024 + tid] = (cblk * 32 + tid < a.Cout) ? a.stat_shift[cblk * 32 + tid] : 0.f;
-    if (blockIdx.x == 0 && tid < 32 && cblk * 32 + tid < a.Cout)
-      a.stat_part[(long)a.Cout * stat_nchunk * 2 + cblk * 32 + tid] = (double)a.stat_shift[cblk * 32 + tid];
+    for (int i = tid; i < 8 * FS_WAVE_FLOATS; i += 512) stat_lds[i] = 0.f;
     __syncthreads();
   }
-  auto flush_stats = [&]() __attribute__((always_inline)) {
-    // slot (row = lane >> 4, r) summed over the eight waves in wave order: channel cblk*32 + cu(r) + 4*(row >> 1), partial
-    // index blockIdx.x*2 + (row & 1)
-    __syncthreads();
-    if (tid < 128) {
-      const int i = tid, pair = i & 1, r = (i >> 1) & 15, row = i >> 5;
-      const int c = cblk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (row >> 1);
-      float sum = 0.f;
-#pragma unroll
-      for (int w8 = 0; w8 < 8; ++w8) sum += stat_lds[w8 * 128 + i];
-      if (c < a.Cout) a.stat_part[((long)c * stat_nchunk + blockIdx.x * 2 + (row & 1)) * 2 + pair] = (double)sum;
-    }
-  };
   if (t_begin >= t_end) {
-    if constexpr (STATS) flush_stats();
+    if constexpr (STATS) fs_flush(stat_lds, 8, tid, cblk * 32, a.Cout, a.stat_part, gridDim.x, blockIdx.x);
     return;
   }
 
@@ -372,7 +346,7 @@ __global__ __launch_bounds__(512) void conv3_bf16x3_kernel(X3Args a) {
       sc[r] = has_aff ? a.scale[co] : 1.f;
       sh[r] = has_aff ? a.shift[co] : 0.f;
     }
-    float st_s[STATS ? 16 : 1], st_q[STATS ? 16 : 1];
+    float st_s[STATS ? 16 : 1], st_q[STATS ? 16 : 1], st_n = 0.f;
     if constexpr (STATS) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) st_s[r] = st_q[r] = 0.f;
@@ -381,6 +355,7 @@ __global__ __launch_bounds__(512) void conv3_bf16x3_kernel(X3Args a) {
     for (int t = 0; t < 2; ++t) {
       const int r0 = (wv * 2 + t) * 2 + (l31 >> 4), d = d0 + (r0 >> 3), h = h0 + (r0 & 7), w = w0 + wlane;
       const int ok = (int)(d < a.D) & (int)(h < a.H) & (int)(w < a.W);
+      if constexpr (STATS) st_n += (float)ok;
       const int voff = ((d * a.H + h) * a.W + w + (cblk * 32 + 4 * half) * cstride) * 4;
       float rp[16], rq[16];
       if (has_pre) {
@@ -405,7 +380,11 @@ __global__ __launch_bounds__(512) void conv3_bf16x3_kernel(X3Args a) {
         v = act_apply(v, a.slope);
         if (has_post) v += rq[r];
         if constexpr (STATS) {
-          const float dlt = ok ? v - stat_lds[1024 + cu + 4 * half] : 0.f;
+          if (stat_first && t == 0) {   // the wave's first tile: the shift of (half, r) = what lane 0 of the half produced
+            const float kf = fs_half_first(v, half);
+            if ((lane & 31) == 0) fs_slot(stat_w, half, r)[0] = kf;
+          }
+          const float dlt = ok ? v - fs_slot(stat_w, half, r)[0] : 0.f;
           st_s[r] += dlt;
           st_q[r] = fmaf(dlt, dlt, st_q[r]);
         }
@@ -419,17 +398,22 @@ __global__ __launch_bounds__(512) void conv3_bf16x3_kernel(X3Args a) {
     if constexpr (STATS) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float rs = row16_sum(st_s[r]), rq2 = row16_sum(st_q[r]);
-        if ((lane & 15) == 0) {
-          float* slot = stat_lds + wv * 128 + ((lane >> 4) * 16 + r) * 2;
-          atomicAdd(slot, rs);          // ds_add_f32 without return: no LDS round trip (still one writer per slot)      // wave-private slot, one writer lane per slot
-          atomicAdd(slot + 1, rq2);
+        const float rs = fs_half_sum(st_s[r]), rq2 = fs_half_sum(st_q[r]);
+        if ((lane & 31) == 0) {
+          atomicAdd(fs_slot(stat_w, half, r) + 1, rs);    // ds_add_f32 without return; wave-private slot, one writer lane
+          atomicAdd(fs_slot(stat_w, half, r) + 2, rq2);
         }
       }
+      const float rn = fs_half_sum(st_n);
+      if ((lane & 31) == 0) atomicAdd(stat_w + 96 + half, rn);
+      stat_first = false;
     }
     n = nn; d0 = nd0; h0 = nh0; w0 = nw0;
   }
-  if constexpr (STATS) flush_stats();
+  if constexpr (STATS) {
+    __syncthreads();
+    fs_flush(stat_lds, 8, tid, cblk * 32, a.Cout, a.stat_part, gridDim.x, blockIdx.x);
+  }
 }
 
 // wx[cblk][chunk][tap][term][lane][j] (bf16): lane (r = lane & 31, h = lane >> 5) holds A[row = output channel
@@ -492,8 +476,8 @@ int x3_grid(long tiles, int cblks) {
 }
 
 int x3_launch(const float* x, const void* wx, float* y, const float* scale, const float* shift, const float* res_pre,
-              const float* res_post, float slope, const float* stat_shift, double* stat_part, int N, int Cin, int Cout,
-              int D, int H, int W, hipStream_t stream) {
+              const float* res_post, float slope, double* stat_part, int N, int Cin, int Cout, int D, int H, int W,
+              hipStream_t stream) {
   DCA_REQUIRE(x && wx && y && N > 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0);
   DCA_REQUIRE((scale == nullptr) == (shift == nullptr));
   DCA_REQUIRE((long)Cin * D * H * W * 4 < 0x7ffffff0L && (long)Cout * D * H * W * 4 < 0x7ffffff0L);  // 32-bit byte offsets inside one sample
@@ -504,7 +488,7 @@ int x3_launch(const float* x, const void* wx, float* y, const float* scale, cons
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.NCH = (Cin + 15) / 16;
   a.D = D; a.H = H; a.W = W;
   a.nTD = cdiv(D, TD); a.nTH = cdiv(H, TH); a.nTW = cdiv(W, TW);
-  a.stat_shift = stat_shift; a.stat_part = stat_part;
+  a.stat_part = stat_part;
   const long tiles = (long)N * a.nTD * a.nTH * a.nTW;
   DCA_REQUIRE(tiles < 0x7fffffffL && (Cout + 31) / 32 <= 65535);
   const bool vec = (W % 4 == 0) && ((((uintptr_t)x) & 15) == 0);
@@ -524,21 +508,21 @@ int x3_launch(const float* x, const void* wx, float* y, const float* scale, cons
 extern "C" int dca_conv3d_x3_forward(const float* x, const void* wx, float* y, const float* scale, const float* shift,
                                      const float* res_pre, const float* res_post, float slope, int N, int Cin, int Cout,
                                      int D, int H, int W, hipStream_t stream) {
-  return x3_launch(x, wx, y, scale, shift, res_pre, res_post, slope, nullptr, nullptr, N, Cin, Cout, D, H, W, stream);
+  return x3_launch(x, wx, y, scale, shift, res_pre, res_post, slope, nullptr, N, Cin, Cout, D, H, W, stream);
 }
 
-// nchunk of the statistics dca_conv3d_x3_forward_stats produces (2 per workgroup of the launch it will make)
+// nchunk of the statistics dca_conv3d_x3_forward_stats produces (one partial per workgroup of the launch it will make)
 extern "C" long dca_conv3d_x3_stats_chunks(int N, int Cout, int D, int H, int W) {
   if (N <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
   const long tiles = (long)N * cdiv(D, TD) * cdiv(H, TH) * cdiv(W, TW);
-  return 2L * x3_grid(tiles, (Cout + 31) / 32);
+  return x3_grid(tiles, (Cout + 31) / 32);
 }
 
-// y = conv(x, w) (no epilogue) plus the BatchNorm batch statistics of y: part (Cout*nchunk*2 + Cout doubles, nchunk =
-// dca_conv3d_x3_stats_chunks) in the layout of dca_bn_stats with K_c = stat_shift[c], ready for dca_bn_finalize
-extern "C" int dca_conv3d_x3_forward_stats(const float* x, const void* wx, float* y, const float* stat_shift,
-                                           double* stat_part, int N, int Cin, int Cout, int D, int H, int W,
-                                           hipStream_t stream) {
-  DCA_REQUIRE(stat_shift && stat_part);
-  return x3_launch(x, wx, y, nullptr, nullptr, nullptr, nullptr, 1.f, stat_shift, stat_part, N, Cin, Cout, D, H, W, stream);
+// y = conv(x, w) (no epilogue) plus the BatchNorm batch statistics of y: part (Cout * nchunk * 4 doubles, nchunk =
+// dca_conv3d_x3_stats_chunks) = one {K, n, sum (y - K), sum (y - K)^2} per (channel, workgroup), for
+// dca_bn_finalize_centered (bn_fused_stats.h)
+extern "C" int dca_conv3d_x3_forward_stats(const float* x, const void* wx, float* y, double* stat_part, int N, int Cin,
+                                           int Cout, int D, int H, int W, hipStream_t stream) {
+  DCA_REQUIRE(stat_part);
+  return x3_launch(x, wx, y, nullptr, nullptr, nullptr, nullptr, 1.f, stat_part, N, Cin, Cout, D, H, W, stream);
 }

@@ -33,6 +33,7 @@
 // with the MFMAs (11 instructions per channel pair), the pass epilogue runs at the end of the compute slot, and a load
 // slot is nothing but waits, register moves and LDS stores.
 #include "dca_common.h"
+#include "bn_fused_stats.h"
 #include "../../include/dca_hip.h"
 
 typedef __bf16 dx_bf16x8 __attribute__((ext_vector_type(8)));
@@ -84,20 +85,10 @@ struct DxArgs {
   int N, Cin, Cout, NCH;
   int Di, Hi, Wi;
   int nTD, nTH, nTW;
-  const float* stat_shift;   // STATS: per-channel shift K_c (Cout floats)
-  double* stat_part;         // STATS: part[(c*nchunk + i)*2 + {0,1}], nchunk = 2 * gridDim.x; K_c at the end
+  double* stat_part;         // STATS: one partial {K, n, s, q} per (channel, workgroup): bn_fused_stats.h
 };
 
-constexpr int STAT_LDS = 8 * 4 * 16 * 2 * 4 + 128;   // [wave][16-lane row][r][sum, sum of squares] floats + 32 shifts
-
-// sum over the 16 lanes of a DPP row, result in every lane of the row
-__device__ __forceinline__ float dx_row16_sum(float x) {
-  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xF, 0xF, true));   // row_half_mirror
-  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xF, 0xF, true));   // row_mirror
-  return x;
-}
+constexpr int STAT_LDS = 8 * FS_WAVE_FLOATS * 4;
 
 __device__ __forceinline__ unsigned dx_pack2(float a, float b) {   // v_cvt_pk_bf16_f32
   typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -148,38 +139,29 @@ __global__ __launch_bounds__(512) void deconv3_bf16x3_kernel(DxArgs a) {
   const int nx = gridDim.x >= 8 ? 8 : 1, xcd = blockIdx.x % nx;
   const int cnt = (gridDim.x - xcd + nx - 1) / nx;
   const int t_begin = (int)(T * xcd / nx) + blockIdx.x / nx, t_end = (int)(T * (xcd + 1) / nx), t_step = cnt;
-  const int stat_nchunk = 2 * gridDim.x;
-  if constexpr (STATS) {
-    for (int i = tid; i < 1024; i += 512) stat_lds[i] = 0.f;
-    if (tid < 32) stat_lds[1024 + tid] = tid < a.Cout ? a.stat_shift[tid] : 0.f;
-    if (blockIdx.x == 0 && tid < a.Cout) a.stat_part[(long)a.Cout * stat_nchunk * 2 + tid] = (double)a.stat_shift[tid];
-    __syncthreads();
-  }
-  float st_s[STATS ? 16 : 1], st_q[STATS ? 16 : 1];
+  float* stat_w = stat_lds + wv * FS_WAVE_FLOATS;   // this wave's slots
+  bool stat_first = true;
+  float st_s[STATS ? 16 : 1], st_q[STATS ? 16 : 1], st_n = 0.f;
   if constexpr (STATS) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) st_s[r] = st_q[r] = 0.f;
+    for (int i = tid; i < 8 * FS_WAVE_FLOATS; i += 512) stat_lds[i] = 0.f;
+    __syncthreads();
   }
   auto flush_stats = [&]() __attribute__((always_inline)) {
-    // lanes of a 16-lane row reduced by DPP, then slot (row = lane >> 4, r) summed over the eight waves in wave order:
-    // channel cu(r) + 4*(row >> 1), partial index blockIdx.x*2 + (row & 1)
+    // per-lane running sums -> wave-private slots (DPP reduction over the wave half), then the workgroup's partial
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float rs = dx_row16_sum(st_s[r]), rq2 = dx_row16_sum(st_q[r]);
-      if ((lane & 15) == 0) {
-        stat_lds[wv * 128 + ((lane >> 4) * 16 + r) * 2] = rs;
-        stat_lds[wv * 128 + ((lane >> 4) * 16 + r) * 2 + 1] = rq2;
+      const float rs = fs_half_sum(st_s[r]), rq2 = fs_half_sum(st_q[r]);
+      if ((lane & 31) == 0) {
+        fs_slot(stat_w, half, r)[1] = rs;
+        fs_slot(stat_w, half, r)[2] = rq2;
       }
     }
+    const float rn = fs_half_sum(st_n);
+    if ((lane & 31) == 0) stat_w[96 + half] = rn;
     __syncthreads();
-    if (tid < 128) {
-      const int i = tid, pair = i & 1, r = (i >> 1) & 15, row = i >> 5;
-      const int c = (r & 3) + 8 * (r >> 2) + 4 * (row >> 1);
-      float sum = 0.f;
-#pragma unroll
-      for (int w8 = 0; w8 < 8; ++w8) sum += stat_lds[w8 * 128 + i];
-      if (c < a.Cout) a.stat_part[((long)c * stat_nchunk + blockIdx.x * 2 + (row & 1)) * 2 + pair] = (double)sum;
-    }
+    fs_flush(stat_lds, 8, tid, 0, a.Cout, a.stat_part, gridDim.x, blockIdx.x);
   };
   if (t_begin >= t_end) {
     if constexpr (STATS) flush_stats();
@@ -429,12 +411,18 @@ __global__ __launch_bounds__(512) void deconv3_bf16x3_kernel(DxArgs a) {
           if constexpr (STATS) {   // per-lane running sums (reduced over lanes and waves once, at the end of the kernel)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const float k = stat_lds[1024 + (r & 3) + 8 * (r >> 2) + 4 * half];
+              if (stat_first) {   // the wave's first pass: the shift of (half, r) = what lane 0 of the half produced
+                const float kf = fs_half_first(acc[0][r], half);
+                if ((lane & 31) == 0) fs_slot(stat_w, half, r)[0] = kf;
+              }
+              const float k = fs_slot(stat_w, half, r)[0];
               const float d0 = ok ? acc[0][r] - k : 0.f, d1 = ok ? acc[1][r] - k : 0.f;
               const float d2 = ok ? acc[2][r] - k : 0.f, d3 = ok ? acc[3][r] - k : 0.f;
               st_s[r] += (d0 + d1) + (d2 + d3);
               st_q[r] += fmaf(d0, d0, d1 * d1) + fmaf(d2, d2, d3 * d3);
             }
+            st_n += 4.f * (float)ok;
+            stat_first = false;
           }
         } else {
           const __amdgpu_buffer_rsrc_t pr = dca_rsrc((has_pre ? a.res_pre : a.y) + (long)cur.n * osample, osample * 4);
@@ -521,8 +509,8 @@ int dx_grid(long tiles) {
 }
 
 int dx_launch(const float* x, const void* wx, float* y, const float* scale, const float* shift, const float* res_pre,
-              const float* res_post, float slope, const float* stat_shift, double* stat_part, int N, int Cin, int Cout,
-              int Di, int Hi, int Wi, hipStream_t stream) {
+              const float* res_post, float slope, double* stat_part, int N, int Cin, int Cout, int Di, int Hi, int Wi,
+              hipStream_t stream) {
   DCA_REQUIRE(x && wx && y && N > 0 && Cin > 0 && Cout > 0 && Cout <= 32 && Di > 0 && Hi > 0 && Wi > 0);
   DCA_REQUIRE((scale == nullptr) == (shift == nullptr));
   DCA_REQUIRE(Wi % 4 == 0 && ((((uintptr_t)x | (uintptr_t)wx) & 15) == 0));
@@ -534,7 +522,7 @@ int dx_launch(const float* x, const void* wx, float* y, const float* scale, cons
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.NCH = (Cin + 15) / 16;
   a.Di = Di; a.Hi = Hi; a.Wi = Wi;
   a.nTD = cdiv(Di, TD); a.nTH = cdiv(Hi, TH); a.nTW = cdiv(Wi, TW);
-  a.stat_shift = stat_shift; a.stat_part = stat_part;
+  a.stat_part = stat_part;
   const long tiles = (long)N * a.nTD * a.nTH * a.nTW;
   DCA_REQUIRE(tiles < 0x7fffffffL);
   const bool stats = stat_part != nullptr;
@@ -552,20 +540,19 @@ int dx_launch(const float* x, const void* wx, float* y, const float* scale, cons
 extern "C" int dca_deconv3d_x3_forward(const float* x, const void* wx, float* y, const float* scale, const float* shift,
                                        const float* res_pre, const float* res_post, float slope, int N, int Cin, int Cout,
                                        int Di, int Hi, int Wi, hipStream_t stream) {
-  return dx_launch(x, wx, y, scale, shift, res_pre, res_post, slope, nullptr, nullptr, N, Cin, Cout, Di, Hi, Wi, stream);
+  return dx_launch(x, wx, y, scale, shift, res_pre, res_post, slope, nullptr, N, Cin, Cout, Di, Hi, Wi, stream);
 }
 
-// nchunk of the statistics dca_deconv3d_x3_forward_stats produces (2 per workgroup of the launch it will make)
+// nchunk of the statistics dca_deconv3d_x3_forward_stats produces (one partial per workgroup of the launch it will make)
 extern "C" long dca_deconv3d_x3_stats_chunks(int N, int Di, int Hi, int Wi) {
   if (N <= 0 || Di <= 0 || Hi <= 0 || Wi <= 0) return 0;
-  return 2L * dx_grid((long)N * cdiv(Di, TD) * cdiv(Hi, TH) * cdiv(Wi, TW));
+  return dx_grid((long)N * cdiv(Di, TD) * cdiv(Hi, TH) * cdiv(Wi, TW));
 }
 
-// y = deconv(x, w) (no epilogue) plus the BatchNorm batch statistics of y: part (Cout*nchunk*2 + Cout doubles) in the
-// layout of dca_bn_stats with K_c = stat_shift[c]
-extern "C" int dca_deconv3d_x3_forward_stats(const float* x, const void* wx, float* y, const float* stat_shift,
-                                             double* stat_part, int N, int Cin, int Cout, int Di, int Hi, int Wi,
-                                             hipStream_t stream) {
-  DCA_REQUIRE(stat_shift && stat_part);
-  return dx_launch(x, wx, y, nullptr, nullptr, nullptr, nullptr, 1.f, stat_shift, stat_part, N, Cin, Cout, Di, Hi, Wi, stream);
+// y = deconv(x, w) (no epilogue) plus the BatchNorm batch statistics of y: part (Cout * nchunk * 4 doubles) = one
+// {K, n, sum (y - K), sum (y - K)^2} per (channel, workgroup), for dca_bn_finalize_centered (bn_fused_stats.h)
+extern "C" int dca_deconv3d_x3_forward_stats(const float* x, const void* wx, float* y, double* stat_part, int N, int Cin,
+                                             int Cout, int Di, int Hi, int Wi, hipStream_t stream) {
+  DCA_REQUIRE(stat_part);
+  return dx_launch(x, wx, y, nullptr, nullptr, nullptr, nullptr, 1.f, stat_part, N, Cin, Cout, Di, Hi, Wi, stream);
 }

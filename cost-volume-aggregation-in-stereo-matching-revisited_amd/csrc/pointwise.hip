@@ -89,6 +89,46 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const double* __restric
   stats[3 * C + c] = b - mean * g * invstd;
 }
 
+// Training-mode finalize for the statistics the convolution kernels emit themselves (dca_*_forward_stats): partial i of
+// channel c is {K, n, s, q} = (its own shift, element count, sum of (y - K), sum of (y - K)^2), each partial centred on a
+// value of its own data (so no partial loses its variance to a large common mean).  All partials are re-centred on the
+// first one's K in double: s' = s + n dk, q' = q + 2 dk s + n dk^2 with dk = K_i - K_ref.
+__global__ __launch_bounds__(64) void bn_finalize_centered_kernel(const double* __restrict__ part, int nchunk,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
+                                   float eps, float* __restrict__ stats, int C) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  const double* p = part + (long)c * nchunk * 4;
+  const double kref = p[0];
+  double n = 0.0, s = 0.0, q = 0.0;
+  for (int i = lane; i < nchunk; i += 64) {
+    const double ki = p[i * 4 + 0], ni = p[i * 4 + 1], si = p[i * 4 + 2], qi = p[i * 4 + 3];
+    const double dk = ki - kref;
+    n += ni;
+    s += si + ni * dk;
+    q += qi + 2.0 * dk * si + ni * dk * dk;
+  }
+  n = wave_sum_d(n);
+  s = wave_sum_d(s);
+  q = wave_sum_d(q);
+  if (lane != 0) return;
+  const double ms = s / n;
+  double v = q / n - ms * ms;
+  if (v < 0.0) v = 0.0;
+  const float mean = (float)(kref + ms), var = (float)v;
+  if (running_mean) {
+    const double unb = n > 1.0 ? v * n / (n - 1.0) : v;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+  }
+  const float invstd = 1.0f / sqrtf(var + eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  stats[c] = mean;
+  stats[C + c] = invstd;
+  stats[2 * C + c] = g * invstd;
+  stats[3 * C + c] = b - mean * g * invstd;
+}
+
 // z = act(scale[c]*y + shift[c] + res_pre) + res_post
 __global__ void bn_apply_kernel(const float* __restrict__ y, const float* __restrict__ stats,
                                 const float* __restrict__ res_pre, const float* __restrict__ res_post,
@@ -644,6 +684,15 @@ extern "C" int dca_bn_finalize(const double* part, int nchunk, double count, con
   DCA_REQUIRE(stats && C > 0 && (training ? (part != nullptr && nchunk > 0) : (running_mean && running_var)));
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, stream, part, nchunk, count, gamma, beta,
                      running_mean, running_var, momentum, eps, training, stats, C);
+  return dca_launch_status();
+}
+
+extern "C" int dca_bn_finalize_centered(const double* part, int nchunk, const float* gamma, const float* beta,
+                                        float* running_mean, float* running_var, float momentum, float eps, float* stats,
+                                        int C, hipStream_t stream) {
+  DCA_REQUIRE(part && nchunk > 0 && stats && C > 0 && ((running_mean == nullptr) == (running_var == nullptr)));
+  hipLaunchKernelGGL(bn_finalize_centered_kernel, dim3(C), dim3(64), 0, stream, part, nchunk, gamma, beta, running_mean,
+                     running_var, momentum, eps, stats, C);
   return dca_launch_status();
 }
 

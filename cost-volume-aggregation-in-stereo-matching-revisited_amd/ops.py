@@ -356,19 +356,19 @@ def _out_dims(dims, ksize, stride, transposed):
 
 
 def _conv_sliced(x, x2, w_src, A, B, K, src_ab, flip, ksize, stride, transposed, scale=None, shift=None, slope=1.0,
-                 res_pre=None, res_post=None, stat_shift=None):
+                 res_pre=None, res_post=None, want_stats=False):
     """y = conv(x [, x2]) with A contraction channels and B output channels, as ceil(B / slice) launches that each
     write their channel slice of y (w_src is the PyTorch weight; src_ab / flip as in dca_conv3d_prep_weight).
-    stat_shift (B floats; no epilogue then): returns (y, part) where part holds the BatchNorm batch-statistics partial
-    sums of y emitted by the convolution kernel itself (layout of dca_bn_stats, shift K_c = stat_shift[c]), or
-    (y, None) when the kernel serving this shape has no such form."""
+    want_stats (no epilogue then): returns (y, part) where part holds the BatchNorm batch-statistics partials of y emitted
+    by the convolution kernel itself (B * nchunk * 4 doubles, csrc/bn_fused_stats.h), or (y, None) when the kernel serving
+    this shape has no such form."""
     y, part = _conv_sliced_impl(x, x2, w_src, A, B, K, src_ab, flip, ksize, stride, transposed, scale, shift, slope,
-                                res_pre, res_post, stat_shift)
-    return y if stat_shift is None else (y, part)
+                                res_pre, res_post, want_stats)
+    return (y, part) if want_stats else y
 
 
 def _conv_sliced_impl(x, x2, w_src, A, B, K, src_ab, flip, ksize, stride, transposed, scale, shift, slope, res_pre,
-                      res_post, stat_shift):
+                      res_post, want_stats):
     N = x.shape[0]
     Di, Hi, Wi = x.shape[2:]
     Do, Ho, Wo = _out_dims((Di, Hi, Wi), ksize, stride, transposed)
@@ -384,11 +384,11 @@ def _conv_sliced_impl(x, x2, w_src, A, B, K, src_ab, flip, ksize, stride, transp
             return w3
         wx = _memo(("x3prep", A, B, int(src_ab), int(flip)), (w_src,), build_x3,
                    (1, A, B, 0, 0, 27, int(src_ab), int(flip), B, 0))
-        if stat_shift is not None:
+        if want_stats:
             nchunk = lib.dca_conv3d_x3_stats_chunks(N, B, Di, Hi, Wi)
-            part = torch.empty((B * nchunk * 2 + B,), device=x.device, dtype=torch.float64)
-            _chk(lib.dca_conv3d_x3_forward_stats(_ptr(x), _ptr(wx), _ptr(y), _ptr(stat_shift), _ptr(part), N, A, B, Di, Hi,
-                                                 Wi, _stream()), "dca_conv3d_x3_forward_stats")
+            part = torch.empty((B * nchunk * 4,), device=x.device, dtype=torch.float64)
+            _chk(lib.dca_conv3d_x3_forward_stats(_ptr(x), _ptr(wx), _ptr(y), _ptr(part), N, A, B, Di, Hi, Wi, _stream()),
+                 "dca_conv3d_x3_forward_stats")
             return y, part
         _chk(lib.dca_conv3d_x3_forward(_ptr(x), _ptr(wx), _ptr(y), _ptr(scale), _ptr(shift), _ptr(res_pre),
                                        _ptr(res_post), float(slope), N, A, B, Di, Hi, Wi, _stream()),
@@ -402,11 +402,11 @@ def _conv_sliced_impl(x, x2, w_src, A, B, K, src_ab, flip, ksize, stride, transp
             return w3
         wx = _memo(("x3prep", A, B, int(src_ab), int(flip)), (w_src,), build_dx3,
                    (1, A, B, 0, 0, 27, int(src_ab), int(flip), B, 0))
-        if stat_shift is not None:
+        if want_stats:
             nchunk = lib.dca_deconv3d_x3_stats_chunks(N, Di, Hi, Wi)
-            part = torch.empty((B * nchunk * 2 + B,), device=x.device, dtype=torch.float64)
-            _chk(lib.dca_deconv3d_x3_forward_stats(_ptr(x), _ptr(wx), _ptr(y), _ptr(stat_shift), _ptr(part), N, A, B, Di,
-                                                   Hi, Wi, _stream()), "dca_deconv3d_x3_forward_stats")
+            part = torch.empty((B * nchunk * 4,), device=x.device, dtype=torch.float64)
+            _chk(lib.dca_deconv3d_x3_forward_stats(_ptr(x), _ptr(wx), _ptr(y), _ptr(part), N, A, B, Di, Hi, Wi,
+                                                   _stream()), "dca_deconv3d_x3_forward_stats")
             return y, part
         _chk(lib.dca_deconv3d_x3_forward(_ptr(x), _ptr(wx), _ptr(y), _ptr(scale), _ptr(shift), _ptr(res_pre),
                                          _ptr(res_post), float(slope), N, A, B, Di, Hi, Wi, _stream()),
@@ -416,9 +416,9 @@ def _conv_sliced_impl(x, x2, w_src, A, B, K, src_ab, flip, ksize, stride, transp
         S = Do * Ho * Wo
         C2 = 0 if x2 is None else x2.shape[1]
         part = None
-        if stat_shift is not None:
+        if want_stats:
             nchunk = lib.dca_conv1_x3_stats_chunks(N, S)
-            part = torch.empty((B * nchunk * 2 + B,), device=x.device, dtype=torch.float64)
+            part = torch.empty((B * nchunk * 4,), device=x.device, dtype=torch.float64)
         for b0 in range(0, B, 32):
             bn = min(32, B - b0)
 
@@ -430,8 +430,8 @@ def _conv_sliced_impl(x, x2, w_src, A, B, K, src_ab, flip, ksize, stride, transp
             wf = _memo(("c1x3prep", A, B, int(src_ab), b0, bn), (w_src,), build_c1,
                        (2, A, bn, 0, 0, 1, int(src_ab), 0, B, b0))
             if part is not None:
-                _chk(lib.dca_conv1_x3_forward_stats(_ptr(x), _ptr(x2), _ptr(wf), _ptr(y), _ptr(stat_shift), _ptr(part), N,
-                                                    C1, C2, bn, B, b0, S, _stream()), "dca_conv1_x3_forward_stats")
+                _chk(lib.dca_conv1_x3_forward_stats(_ptr(x), _ptr(x2), _ptr(wf), _ptr(y), _ptr(part), N, C1, C2, bn, B, b0,
+                                                    S, _stream()), "dca_conv1_x3_forward_stats")
             else:
                 _chk(lib.dca_conv1_x3_forward(_ptr(x), _ptr(x2), _ptr(wf), _ptr(y), _ptr(scale), _ptr(shift),
                                               _ptr(res_pre), _ptr(res_post), float(slope), N, C1, C2, bn, B, b0, S,
@@ -459,7 +459,7 @@ def conv3d_prepared(x, wt, A, Apad, B, ksize, stride, transposed):
 
 
 def _conv_forward_impl(x, x2, weight, stride, transposed, scale=None, shift=None, slope=1.0, res_pre=None,
-                       res_post=None, stat_shift=None):
+                       res_post=None, want_stats=False):
     ksize = weight.shape[2]
     K = ksize ** 3
     if transposed:
@@ -470,7 +470,7 @@ def _conv_forward_impl(x, x2, weight, stride, transposed, scale=None, shift=None
         src_ab = 0
     assert x.shape[1] + (x2.shape[1] if x2 is not None else 0) == Cin, "conv3d: channel mismatch"
     return _conv_sliced(x, x2, weight, Cin, Cout, K, src_ab, 0, ksize, stride, transposed, scale, shift, slope,
-                        res_pre, res_post, stat_shift)
+                        res_pre, res_post, want_stats)
 
 
 def _wgrad(x, dy, dw_view_ptr_tensor, dst_offset, Cx, Cy, ksize, stride, s_cy, s_cx):
@@ -533,19 +533,18 @@ class _Conv3d(torch.autograd.Function):
     Optional second input x2 = implicit channel concat for the 1x1x1 `fuse` conv."""
 
     @staticmethod
-    def forward(ctx, x, x2, weight, stride, transposed, stat_shift=None):
-        """stat_shift (Cout floats, e.g. a BatchNorm running mean): returns (y, part) -- part = the BatchNorm
-        batch-statistics partial sums of y from the convolution kernel's own epilogue (not differentiable), or None
-        where the kernel serving this shape cannot produce them"""
+    def forward(ctx, x, x2, weight, stride, transposed, want_stats=False):
+        """want_stats: returns (y, part) -- part = the BatchNorm batch-statistics partials of y from the convolution
+        kernel's own epilogue (not differentiable; csrc/bn_fused_stats.h), empty where the kernel serving this shape
+        cannot produce them"""
         x, weight = _req(x, "conv3d"), _req(weight, "conv3d.weight")
         x2 = _opt(x2, "conv3d.x2")
         ctx.save_for_backward(x, x2, weight)
         ctx.meta = (stride, transposed)
         with torch.cuda.device_of(x):
-            if stat_shift is None:
+            if not want_stats:
                 return _conv_forward_impl(x, x2, weight, stride, transposed)
-            y, part = _conv_forward_impl(x, x2, weight, stride, transposed,
-                                         stat_shift=_req(stat_shift.detach(), "conv3d.stat_shift"))
+            y, part = _conv_forward_impl(x, x2, weight, stride, transposed, want_stats=True)
         if part is None:
             part = torch.empty((0,), device=x.device, dtype=torch.float64)
         ctx.mark_non_differentiable(part)
@@ -600,15 +599,6 @@ class _Conv3d(torch.autograd.Function):
         return gx, gx2, gw, None, None, None
 
 
-class _Conv3dStats:
-    """Conv3d(k=3, s=1, p=1, bias=False) whose kernel also emits the BatchNorm batch statistics of its output:
-    apply(x, weight, shift) -> (y, part).  (`_Conv3d` with a stat_shift; kept as the test entry point.)"""
-
-    @staticmethod
-    def apply(x, weight, shift):
-        return _Conv3d.apply(x, None, weight, 1, False, shift)
-
-
 def conv3d(x, weight, stride=1, transposed=False, x2=None):
     if (not transposed and x2 is None and weight.shape[0] == 1 and weight.shape[2] == 3 and int(stride) == 1
             and weight.shape[1] in (32, 64)):
@@ -629,18 +619,20 @@ def conv3d_fused_inference(x, weight, stride, transposed, scale, shift, slope, r
 # ------------------------------------------------------------------------------------------------
 def bn_stats_vector(y, gamma, beta, running_mean, running_var, training, momentum, eps, part=None):
     """[mean | invstd | scale | shift] (4*C floats); updates the running stats in place when training.
-    part: partial sums the producing convolution already emitted (dca_conv3d_x3_forward_stats), or None."""
+    part: partial statistics the producing convolution already emitted (dca_*_forward_stats), or None."""
     N, C = y.shape[0], y.shape[1]
     S = y[0, 0].numel()
     stats = torch.empty((4 * C,), device=y.device, dtype=torch.float32)
     lib = _L()
     if training:
-        if part is not None:
-            nchunk = (part.numel() - C) // (2 * C)
-        else:
-            nchunk = lib.dca_bn_num_chunks(C, S)
-            part = torch.empty((C * nchunk * 2 + C,), device=y.device, dtype=torch.float64)   # partial sums + C shifts
-            _chk(lib.dca_bn_stats(_ptr(y), _ptr(part), N, C, S, _stream()), "dca_bn_stats")
+        if part is not None:     # one self-centred partial {K, n, s, q} per (channel, workgroup) of the producing conv
+            _chk(lib.dca_bn_finalize_centered(_ptr(part), part.numel() // (4 * C), _ptr(gamma), _ptr(beta),
+                                              _ptr(running_mean), _ptr(running_var), float(momentum), float(eps),
+                                              _ptr(stats), C, _stream()), "dca_bn_finalize_centered")
+            return stats
+        nchunk = lib.dca_bn_num_chunks(C, S)
+        part = torch.empty((C * nchunk * 2 + C,), device=y.device, dtype=torch.float64)   # partial sums + C shifts
+        _chk(lib.dca_bn_stats(_ptr(y), _ptr(part), N, C, S, _stream()), "dca_bn_stats")
         _chk(lib.dca_bn_finalize(_ptr(part), nchunk, float(N * S), _ptr(gamma), _ptr(beta), _ptr(running_mean),
                                  _ptr(running_var), float(momentum), float(eps), 1, _ptr(stats), C, _stream()),
              "dca_bn_finalize")
@@ -843,7 +835,7 @@ class batched_bn_counters:
 
 def bn_act(y, bn, slope=1.0, res_pre=None, res_post=None, stats_part=None):
     """Applies the nn.BatchNorm3d module `bn` (parameters/buffers only; its forward is never called).
-    stats_part: batch-statistics partial sums of y from the producing convolution (`_Conv3dStats`), if it made them."""
+    stats_part: batch-statistics partial sums of y from the producing convolution (`_Conv3d` with want_stats), if it made them."""
     momentum = 0.1 if bn.momentum is None else bn.momentum
     training = bn.training or bn.running_mean is None
     if _lp_dtype() is not None:
@@ -907,11 +899,10 @@ def convbn3d(x, conv, bn, slope=1.0, res_pre=None, res_post=None, x2=None):
         C = bn.num_features
         return conv3d_fused_inference(xx, conv.weight, stride, transposed, stats[2 * C:3 * C], stats[3 * C:], slope,
                                       res_pre, res_post, x2)
-    if (BN_FUSE and bn.training and bn.running_mean is not None and conv.weight.shape[0 if not transposed else 1] > 1
-            and _lp_dtype() is None):
+    if BN_FUSE and bn.training and conv.weight.shape[0 if not transposed else 1] > 1 and _lp_dtype() is None:
         # the convolution kernel emits the batch statistics of its own output where it has such a form (the bf16x3 family):
         # no separate pass over y
-        y, part = _Conv3d.apply(x, x2, conv.weight, int(stride), bool(transposed), bn.running_mean)
+        y, part = _Conv3d.apply(x, x2, conv.weight, int(stride), bool(transposed), True)
         return bn_act(y, bn, slope, res_pre, res_post, part if part.numel() else None)
     y = conv3d(x, conv.weight, stride, transposed, x2)
     return bn_act(y, bn, slope, res_pre, res_post)

@@ -23,7 +23,7 @@ extern "C" {
 
 /* Bumped whenever an argument list below changes; the ctypes loader (_lib.py) refuses a library built from another
  * version of this header. */
-#define DCA_ABI_VERSION 8
+#define DCA_ABI_VERSION 9
 int dca_abi_version(void);
 
 /* storage types of the reduced-precision inference path (0 = fp32) */
@@ -156,22 +156,26 @@ int dca_deconv3d_x3_forward(const float* x, const void* wx, float* y, const floa
                             int Hi, int Wi, hipStream_t stream);
 
 /* The same convolution without epilogue, fused with the BatchNorm batch statistics of its output (training-mode
- * convbn_3d, models/submodule.py:121-124): part (Cout*nchunk*2 + Cout doubles, nchunk = dca_conv3d_x3_stats_chunks(...))
- * receives, in the layout of dca_bn_stats, the per-(workgroup, wave, row) partial sums of (y - K_c) and (y - K_c)^2 with
- * K_c = stat_shift[c] (the caller passes the BatchNorm running mean), ready for dca_bn_finalize(part, nchunk, N*D*H*W, ...).
- * Fixed summation order: bitwise reproducible. */
+ * convbn_3d, models/submodule.py:121-124; csrc/bn_fused_stats.h): part (Cout * nchunk * 4 doubles, nchunk =
+ * dca_conv3d_x3_stats_chunks(...)) receives ONE partial per (channel, workgroup), part[(c*nchunk + i)*4 + {0,1,2,3}] =
+ * {K, n, sum (y - K), sum (y - K)^2} with a shift K taken from the partial's own data (no loss of variance for
+ * |mean| >> std); dca_bn_finalize_centered(part, nchunk, ...) re-centres and sums them in double.  Fixed summation order,
+ * a function of the data alone: bitwise reproducible. */
 long dca_conv3d_x3_stats_chunks(int N, int Cout, int D, int H, int W);
-int dca_conv3d_x3_forward_stats(const float* x, const void* wx, float* y, const float* stat_shift, double* stat_part,
-                                int N, int Cin, int Cout, int D, int H, int W, hipStream_t stream);
+int dca_conv3d_x3_forward_stats(const float* x, const void* wx, float* y, double* stat_part, int N, int Cin, int Cout,
+                                int D, int H, int W, hipStream_t stream);
 /* The same for the 1x1x1 convolutions (conv1_x3.hip; part covers all CoutTotal channels, every channel slice of a sliced
- * convolution fills its own rows; stat_shift has CoutTotal entries) and the transposed convolution (deconv3d_x3.hip). */
+ * convolution fills its own channels) and the transposed convolution (deconv3d_x3.hip). */
 long dca_conv1_x3_stats_chunks(int N, long S);
-int dca_conv1_x3_forward_stats(const float* x, const float* x2, const void* wfrag, float* y, const float* stat_shift,
-                               double* stat_part, int N, int C1, int C2, int Cout, int CoutTotal, int co_off, long S,
-                               hipStream_t stream);
+int dca_conv1_x3_forward_stats(const float* x, const float* x2, const void* wfrag, float* y, double* stat_part, int N,
+                               int C1, int C2, int Cout, int CoutTotal, int co_off, long S, hipStream_t stream);
 long dca_deconv3d_x3_stats_chunks(int N, int Di, int Hi, int Wi);
-int dca_deconv3d_x3_forward_stats(const float* x, const void* wx, float* y, const float* stat_shift, double* stat_part,
-                                  int N, int Cin, int Cout, int Di, int Hi, int Wi, hipStream_t stream);
+int dca_deconv3d_x3_forward_stats(const float* x, const void* wx, float* y, double* stat_part, int N, int Cin, int Cout,
+                                  int Di, int Hi, int Wi, hipStream_t stream);
+/* [mean | invstd | scale | shift] (4*C floats) from those partials, with the running-statistics update of training-mode
+ * nn.BatchNorm3d (momentum, unbiased variance); running_mean / running_var may both be null. */
+int dca_bn_finalize_centered(const double* part, int nchunk, const float* gamma, const float* beta, float* running_mean,
+                             float* running_var, float momentum, float eps, float* stats, int C, hipStream_t stream);
 
 /* Weight gradient of the 3x3x3 / stride-1 / pad-1 convolution on the bf16 matrix pipe with the same exact three-way
  * bf16 split (conv3d_wgrad_bf16x3.hip); replaces dca_conv3d_wgrad for ksize 3, stride 1 (autograd's dW of the nn.Conv3d

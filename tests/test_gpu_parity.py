@@ -303,23 +303,50 @@ def test_conv3d_stats_fused(case):
     mean_ref = yd.mean(dim=(0, 2, 3, 4))
     var_ref = yd.var(dim=(0, 2, 3, 4), unbiased=False)
     cnt = float(y_ref.numel() // cout)
-    for shift in (torch.zeros(cout), mean_ref.float().cpu() * 0.97):
-        y, part = ops._Conv3d.apply(x1, x2, wg, stride, transposed, shift.to(DEV))
-        assert part.numel() > 0, "this shape should be served by a statistics-emitting kernel"
-        assert torch.equal(y, y_ref)
-        nchunk = (part.numel() - cout) // (2 * cout)
-        p = part[:cout * nchunk * 2].view(cout, nchunk, 2).sum(1)
-        K = part[cout * nchunk * 2:]
-        m1 = p[:, 0] / cnt
-        mean = K + m1
-        var = p[:, 1] / cnt - m1 * m1
-        assert torch.allclose(K.float().cpu(), shift)
-        assert (mean - mean_ref).abs().max().item() <= 2e-6 * mean_ref.abs().max().item() + 1e-6
-        tol = 5e-5 if shift.abs().max() == 0 else 2e-6          # unshifted fp32 partial sums lose digits to the mean
-        assert ((var - var_ref).abs() / var_ref).max().item() <= tol, ((var - var_ref).abs() / var_ref).max().item()
+    y, part = ops._Conv3d.apply(x1, x2, wg, stride, transposed, True)
+    assert part.numel() > 0, "this shape should be served by a statistics-emitting kernel"
+    assert torch.equal(y, y_ref)
+    # fold the self-centred partials {K, n, s, q} the way dca_bn_finalize_centered does
+    p = part.view(cout, -1, 4)
+    K, n, sm, q = p[..., 0], p[..., 1], p[..., 2], p[..., 3]
+    dk = K - K[:, :1]
+    N_tot = n.sum(1)
+    S = (sm + n * dk).sum(1)
+    Q = (q + 2 * dk * sm + n * dk * dk).sum(1)
+    assert torch.all(N_tot == cnt), (N_tot, cnt)
+    mean = K[:, 0] + S / N_tot
+    var = Q / N_tot - (S / N_tot) ** 2
+    assert (mean - mean_ref).abs().max().item() <= 2e-6 * mean_ref.abs().max().item() + 1e-6
+    assert ((var - var_ref).abs() / var_ref).max().item() <= 2e-6, ((var - var_ref).abs() / var_ref).max().item()
+    # the finalize kernel itself, running-statistics update included
+    bn = torch.nn.BatchNorm3d(cout).to(DEV)
+    stats = ops.bn_stats_vector(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, True, 0.1, 1e-5, part)
+    assert (stats[:cout].double() - mean_ref).abs().max().item() <= 2e-6 * mean_ref.abs().max().item() + 1e-6
+    inv_ref = 1.0 / torch.sqrt(var_ref + 1e-5)
+    assert ((stats[cout:2 * cout].double() - inv_ref).abs() / inv_ref).max().item() <= 2e-6
+    assert (bn.running_mean.double() - 0.1 * mean_ref).abs().max().item() <= 1e-6 * (1 + mean_ref.abs().max().item())
+    unb = var_ref * cnt / (cnt - 1)
+    assert ((bn.running_var.double() - (0.9 + 0.1 * unb)).abs() / (0.9 + 0.1 * unb)).max().item() <= 2e-6
     # bitwise reproducible
-    y2, part2 = ops._Conv3d.apply(x1, x2, wg, stride, transposed, shift.to(DEV))
+    y2, part2 = ops._Conv3d.apply(x1, x2, wg, stride, transposed, True)
     assert torch.equal(part, part2)
+
+
+def test_conv3d_stats_fused_large_mean():
+    """|mean| >> std (mean / std ~ 1e3): the partials are centred on values of their own data, so the variance survives"""
+    _, ops = _mods()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 32, 6, 12, 36, generator=g) * 1e-3 + 1.0
+    w = torch.rand(32, 32, 3, 3, 3, generator=g) * 0.1
+    xg, wg = x.to(DEV), w.to(DEV)
+    y, part = ops._Conv3d.apply(xg, None, wg, 1, False, True)
+    yd = y.double()[:, :, 1:-1, 1:-1, 1:-1]        # interior only, for the ratio quoted below (the check uses all of y)
+    assert (yd.mean(dim=(0, 2, 3, 4)).abs() / yd.std(dim=(0, 2, 3, 4))).min().item() > 300
+    var_ref = y.double().var(dim=(0, 2, 3, 4), unbiased=False)
+    bn = torch.nn.BatchNorm3d(32).to(DEV)
+    stats = ops.bn_stats_vector(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, True, 0.1, 0.0, part)
+    inv_ref = 1.0 / torch.sqrt(var_ref)
+    assert ((stats[32:64].double() - inv_ref).abs() / inv_ref).max().item() <= 1e-5
 
 
 def test_convbn3d_training_uses_fused_statistics(monkeypatch):
@@ -859,18 +886,15 @@ def test_graph_replay_matches_eager():
 
 
 def test_training_step_is_bitwise_reproducible():
-    """idempotence: forward + backward twice on the same inputs AND the same module state give bit-identical outputs and
-    gradients (no float atomics anywhere on the path; all cross-workgroup sums are order-fixed).  The BatchNorm buffers are
-    part of that state: the convolution kernels that emit the batch statistics centre their sums on the running mean, so
-    a changed running mean changes the last bits of the batch statistics."""
-    import copy
+    """idempotence: forward + backward twice on the same inputs give bit-identical outputs and gradients (no float
+    atomics anywhere on the path; all cross-workgroup sums are order-fixed; the BatchNorm batch statistics -- also the ones
+    the convolution kernels emit themselves -- are a function of the data alone, not of the running statistics the first
+    run has updated)"""
     from dcanet_amd.models.gwcnet_dca_g import GwcNet
     m = load_seeded(GwcNet(32, use_concat_volume=True)).to(DEV).train()
-    state = copy.deepcopy(m.state_dict())
     fL, fR = gpu(seeded_tensor("hot.fL", (2, 332, 16, 32)), True), gpu(seeded_tensor("hot.fR", (2, 332, 16, 32)), True)
     runs = []
     for _ in range(2):
-        m.load_state_dict(state)
         r = m.hot_path(fL[:, :320], fR[:, :320], fL[:, 320:], fR[:, 320:])
         loss = r["pred4_q"].sum() + r["pred_dca3"].mean() + r["pred1"].square().sum()
         gr = torch.autograd.grad(loss, [fL, fR, m.dres0[0][0].weight, m.cva2.cost_agg.conv3[0].weight,
