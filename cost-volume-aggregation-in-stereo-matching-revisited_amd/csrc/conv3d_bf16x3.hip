@@ -36,6 +36,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef X3_NT
 #define X3_NT 0
 #endif
+// X3_STAMP (debug build, tools/x3_stamps.py): res_post is reinterpreted as an unsigned long long buffer that receives
+// s_memtime stamps of the first 96 phases (8 per phase) of workgroup 0, wave 0
+#ifndef X3_STAMP
+#define X3_STAMP 0
+#endif
+#if X3_STAMP
+#define X3_MARK(i) do { if (stamp_on && stamp_k < 96) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) stamps[stamp_k * 8 + (i)] = t_; } } while (0)
+#else
+#define X3_MARK(i) do { } while (0)
+#endif
 
 namespace {
 
@@ -131,6 +141,12 @@ __global__ __launch_bounds__(512) void conv3_bf16x3_kernel(X3Args a) {
   const long wbytes = (long)P * A_SLAB;
   const __amdgpu_buffer_rsrc_t wr = dca_rsrc((const char*)a.wx + (long)cblk * wbytes, wbytes);
 
+#if X3_STAMP
+  unsigned long long* stamps = (unsigned long long*)a.res_post;
+  a.res_post = nullptr;
+  const bool stamp_on = blockIdx.x == 0 && blockIdx.y == 0 && wv == 0;
+  int stamp_k = 0;
+#endif
   const bool has_aff = a.scale != nullptr, has_pre = a.res_pre != nullptr, has_post = a.res_post != nullptr;
   float4 ra[KA];
   auto load_A = [&](int p) __attribute__((always_inline)) {
@@ -270,6 +286,7 @@ __global__ __launch_bounds__(512) void conv3_bf16x3_kernel(X3Args a) {
       const bool last_of_chunk = kd == 2;
       const bool next_chunk = last_of_chunk && (chunk + 1 < a.NCH);
       const bool next_tile = last_of_chunk && !next_chunk && more_tiles;
+      X3_MARK(0);
       // slab p+1 (in registers since the previous phase) -> the buffer phase p-1 used; then fetch slab p+2
       if (p + 1 < P || more_tiles) store_A(buf ^ 1);
       if (p + 2 < P || more_tiles) load_A(p + 2 < P ? p + 2 : p + 2 - P);
@@ -323,13 +340,22 @@ __global__ __launch_bounds__(512) void conv3_bf16x3_kernel(X3Args a) {
           }
         }
       };
+      X3_MARK(1);
       if (stage) phase(std::true_type{}); else phase(std::false_type{});
+      X3_MARK(2);
       if (stage) {
         __syncthreads();  // every wave is done reading the halo tile of this chunk
+        X3_MARK(3);
         store_B();
+        X3_MARK(4);
       }
       __syncthreads();
+      X3_MARK(5);
+#if X3_STAMP
+      if (p + 1 < P) ++stamp_k;
+#endif
     }
+    X3_MARK(6);
 
     // Epilogue (same contract as conv3d_mfma.hip): y = act(acc * scale + shift + res_pre) + res_post.  The stores
     // drain while the next tile's first phase runs.
@@ -408,6 +434,10 @@ __global__ __launch_bounds__(512) void conv3_bf16x3_kernel(X3Args a) {
       if ((lane & 31) == 0) atomicAdd(stat_w + 96 + half, rn);
       stat_first = false;
     }
+    X3_MARK(7);
+#if X3_STAMP
+    ++stamp_k;
+#endif
     n = nn; d0 = nd0; h0 = nh0; w0 = nw0;
   }
   if constexpr (STATS) {
