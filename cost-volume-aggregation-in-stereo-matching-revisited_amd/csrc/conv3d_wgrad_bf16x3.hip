@@ -30,6 +30,20 @@ typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 int dca_internal_wgrad_reduce(const float* part, float* dw, int nblk, int nCxT, int nCT, int K, int Cy, int Cx,
                               long s_cy, long s_cx, hipStream_t stream);  // conv3d_wgrad.hip
 
+// WX3_STAMP (debug build, tools/wx3_stamps.py): `part` is followed by an unsigned long long stamp buffer (the tool
+// allocates it) that receives s_memtime stamps of the first 64 tiles of workgroup 0, waves 0 and 3
+#ifndef WX3_STAMP
+#define WX3_STAMP 0
+#endif
+#ifndef WX3_LOADS_IN
+#define WX3_LOADS_IN 1
+#endif
+#if WX3_STAMP
+#define WX3_MARK(i) do { if (stamp_on && stamp_k < 64) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) stamps[((wq == 3) * 64 + stamp_k) * 8 + (i)] = t_; } } while (0)
+#else
+#define WX3_MARK(i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int TD = 2, TH = 4, TW = 16;
@@ -153,13 +167,21 @@ __global__ __launch_bounds__(512) void wgrad3_bf16x3_kernel(WX3Args a) {
     }
   };
 
-  // The MFMA phase of one tile for tap group WQ (taps 7*WQ .. 7*WQ+6, < 27).
-  auto mfma_tile = [&](auto WQC) __attribute__((always_inline)) {
+  // The MFMA phase of one tile for tap group WQ (taps 7*WQ .. 7*WQ+6, < 27).  The next tile's global loads are issued
+  // BEHIND the first K-step's MFMAs: in front of the phase the address arithmetic and the memory pipe's back-pressure of
+  // 11 load instructions per thread kept all eight waves -- and the matrix pipe -- busy for 1600-1900 of a tile's 18.9 k
+  // cycles (s_memtime stamps, tools/wx3_stamps.py).
+  auto mfma_tile = [&](auto WQC, bool more, int next_tile) __attribute__((always_inline)) {
     constexpr int WQ = decltype(WQC)::value;
     constexpr int TAP0 = 7 * WQ, TAP1 = (TAP0 + 7 < 27) ? TAP0 + 7 : 27;
     constexpr int R0 = TAP0 / 3, R1 = (TAP1 - 1) / 3;  // (kd, kh) rows this wave touches
 #pragma unroll 1
     for (int i = 0; i < NROW / 2; ++i) {
+      if (WX3_LOADS_IN && i == 1 && more) {
+        int nn, nd0, nh0, nw0;
+        decode(next_tile, nn, nd0, nh0, nw0);
+        load_tile(nn, nd0, nh0, nw0);
+      }
       const int row = grp * (NROW / 2) + i, dl = row / TH, hl = row % TH;
       bf16x8 ay[3];
 #pragma unroll
@@ -212,6 +234,11 @@ __global__ __launch_bounds__(512) void wgrad3_bf16x3_kernel(WX3Args a) {
     }
   };
 
+#if WX3_STAMP
+  unsigned long long* stamps = (unsigned long long*)(a.part + (long)gridDim.x * gridDim.y * 27 * 1024);
+  const bool stamp_on = blockIdx.x == 0 && blockIdx.y == 0 && grp == 0 && (wq == 0 || wq == 3);
+  int stamp_k = 0;
+#endif
   if (t_begin < t_end) {
     int n, d0, h0, w0;
     decode(t_begin, n, d0, h0, w0);
@@ -221,19 +248,28 @@ __global__ __launch_bounds__(512) void wgrad3_bf16x3_kernel(WX3Args a) {
 #pragma unroll 1
     for (int tile = t_begin; tile < t_end; tile += t_step) {
       const bool more = tile + t_step < t_end;
-      if (more) {
+      WX3_MARK(0);
+      if (more && !WX3_LOADS_IN) {
         decode(tile + t_step, n, d0, h0, w0);
         load_tile(n, d0, h0, w0);
       }
+      WX3_MARK(1);
       switch (wq) {
-        case 0: mfma_tile(std::integral_constant<int, 0>{}); break;
-        case 1: mfma_tile(std::integral_constant<int, 1>{}); break;
-        case 2: mfma_tile(std::integral_constant<int, 2>{}); break;
-        default: mfma_tile(std::integral_constant<int, 3>{}); break;
+        case 0: mfma_tile(std::integral_constant<int, 0>{}, more, tile + t_step); break;
+        case 1: mfma_tile(std::integral_constant<int, 1>{}, more, tile + t_step); break;
+        case 2: mfma_tile(std::integral_constant<int, 2>{}, more, tile + t_step); break;
+        default: mfma_tile(std::integral_constant<int, 3>{}, more, tile + t_step); break;
       }
+      WX3_MARK(2);
       __syncthreads();  // every wave is done reading this tile
+      WX3_MARK(3);
       if (more) store_tile();
+      WX3_MARK(4);
       __syncthreads();
+      WX3_MARK(5);
+#if WX3_STAMP
+      ++stamp_k;
+#endif
     }
   }
 
