@@ -1,0 +1,651 @@
+// 3x3x3 stride-1 convolution on the f16 matrix pipe with fp32-grade accuracy ("f16x2" split emulation).
+//
+// Every fp32 operand is first scaled by a power of two taken from its tensor's max |.| (exact; the scaled maximum lies in
+// [2^14, 2^15), inside the f16 range whatever the magnitude of the tensor -- loss gradients of 1e-9 included) and then split
+// into two f16 terms, x 2^e = h + l with h = f16(x 2^e), l = f16(x 2^e - h): 11 + 11 significand bits plus the sign of l,
+// |x 2^e - h - l| <= 2^-22 |x 2^e| (an fp32 operand itself carries a 2^-24 rounding).  A product w*x is evaluated as the
+// three partial products of weight >= 2^-11,
+//     w_h x_h + (w_h x_l + w_l x_h)
+// each exact in the MFMA's fp32 accumulator; the dropped w_l x_l is <= 2^-22 relative.  Three v_mfma_f32_32x32x16_f16
+// replace the six bf16 products of conv3d_bf16x3.hip (and sixteen v_mfma_f32_32x32x2f32 of conv3d_mfma.hip) per 32 input
+// channels, tap and 32-voxel tile: half the matrix-pipe cycles of the bf16x3 kernel, 5.3x fewer than fp32 MFMA.  Against
+// fp64 convolutions the kernel measures the same error as the fp32 MFMA kernel (the fp32 accumulation of 27*Cin products
+// dominates both), tests/test_gpu_parity.py.
+//
+// The operand maxima arrive as device words (bit pattern of max |x| as an fp32 number): the kernels that produce the
+// operands emit them (bn_apply / bn_bwd_apply, pointwise.hip) or dca_amax_f32 computes them; the weight's power of two is
+// chosen by the weight packing kernel and stored behind the packed image.  Nothing is read back by the host.
+//
+// Reference operators served: nn.Conv3d(k=3, s=1, p=1) of convbn_3d (models/submodule.py:121-124) in dres0/dres1,
+// Multi_Aggregation and the cva blocks (models/augment/cva.py:13-55), and their backward-data.
+//
+// Work decomposition (that of conv3d_bf16x3.hip): one workgroup (8 waves) per 4 x 8 x 16 output tile (512 voxels = 16
+// MFMA column tiles, two per wave) and 32 output channels; one workgroup per CU, two waves per SIMD.  Input channels go
+// through LDS in chunks of 16 (one MFMA K): the 6 x 10 x 18 halo tile of the chunk, pre-split into two f16 images laid out
+// [term][k half][voxel][8 f16] so that a lane's B fragment (8 consecutive k of its voxel) is one ds_read_b128 and 16
+// consecutive lanes read 256 contiguous bytes.  The weights arrive pre-scaled, pre-split and pre-swizzled into MFMA A
+// fragments (x2_prep_weight_kernel) and stream through a double-buffered LDS slab of 9 taps (one kd plane) per phase, so
+// a channel chunk is three phases of 54 MFMAs per wave with one barrier each; the next slab / next halo tile are fetched
+// into registers (hardware-predicated buffer loads) while the current phase's MFMAs run.
+#include "dca_common.h"
+#include "bn_fused_stats.h"
+#include <type_traits>
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// Non-temporal output stores (X2_NT=1): y is written once, so it need not displace the halo lines the neighbouring tiles
+// re-read from this XCD's L2 -- 591 -> 568 us on the fused-epilogue 32->32 launch at 48x136x240 in isolation
+// (tools/nt_ablate.sh).  In the network the consumer of y (BatchNorm statistics + apply in training, the next convolution
+// in inference) runs right behind and finds a 200 MB output partly in the 256 MB infinity cache when it was stored with
+// the default policy: training step 37.86 -> 37.38 ms per pair at batch 1, eval forward 7.63 -> 7.51 ms, batch-4 step
+// 143.7 -> 143.4 ms (tools/nt_bench_ab.sh).  So the default is plain stores.
+#ifndef X2_NT
+#define X2_NT 0
+#endif
+// X2_STAMP (debug build, tools/x3_stamps.py, f16x2 build): res_post is reinterpreted as an unsigned long long buffer that receives
+// s_memtime stamps of the first 96 phases (8 per phase) of workgroup 0, wave 0
+#ifndef X2_STAMP
+#define X2_STAMP 0
+#endif
+#if X2_STAMP
+#define X2_MARK(i) do { if (stamp_on && stamp_k < 96) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) stamps[stamp_k * 8 + (i)] = t_; } } while (0)
+#else
+#define X2_MARK(i) do { } while (0)
+#endif
+
+namespace {
+
+constexpr int TD = 4, TH = 8, TW = 16;
+constexpr int ID = TD + 2, IH = TH + 2, IW = TW + 2;
+constexpr int NVOX = ID * IH * IW;                 // 1080 halo voxels
+constexpr int NT = 2;                              // terms per operand
+constexpr int B_TERM = 2 * NVOX * 16;              // bytes of one f16 term image (2 k halves x voxels x 16 B)
+constexpr int B_BYTES = NT * B_TERM;               // 69120
+constexpr int A_SLAB = 9 * NT * 1024;              // 9 taps x 2 terms x (64 lanes x 16 B)
+constexpr int LDS_BYTES = B_BYTES + 2 * A_SLAB;    // 105984 of the CU's 163840
+constexpr int NB_ITEMS = 2 * NVOX;                 // (k half, voxel) staging items of 8 channels (unaligned path)
+constexpr int KB = (NB_ITEMS + 511) / 512;         // 5
+constexpr int NROWS = 2 * ID * IH;                 // 120 (k half, d, h) halo rows: 4 aligned quads + 2 edge voxels each
+constexpr int NQUAD = NROWS * 4, NEDGE = NROWS * 2;  // aligned path: 480 quad items (8 x b128), 240 edge items (8 x b32)
+static_assert(NQUAD <= 512 && NEDGE <= 512, "one quad / edge item per thread");
+constexpr int NA_ITEMS = A_SLAB / 16;              // 1152 b128 per slab
+constexpr int KA = (NA_ITEMS + 511) / 512;         // 3
+
+struct X2Args {
+  const float* x;
+  const unsigned short* wx;
+  float* y;
+  const float* scale;
+  const float* shift;
+  const float* res_pre;
+  const float* res_post;
+  float slope;
+  int N, Cin, Cout, NCH;
+  int D, H, W;
+  int nTD, nTH, nTW;
+  double* stat_part;         // STATS: one partial {K, n, s, q} per (channel, workgroup): bn_fused_stats.h
+  const unsigned* x_amax;    // bit pattern of max |x| (fp32), device word
+  const float* wtail;        // {2^ew, 2^-ew} behind the packed weight image
+  unsigned* y_amax;          // optional: receives the bit pattern of max |y| (zero-initialised device word)
+};
+
+constexpr int STAT_LDS = 8 * FS_WAVE_FLOATS * 4;
+
+// x 2^e = h + l (+ <= 2^-22 relative); `s` = 2^e
+__device__ __forceinline__ void split2(float v, float s, _Float16& h, _Float16& l) {
+  const float u = v * s;          // exact: power of two, scaled maximum < 2^15
+  h = (_Float16)u;
+  l = (_Float16)(u - (float)h);   // the residual is exact in fp32
+}
+
+// power of two that brings a tensor whose max |.| has the bit pattern `bits` into [2^14, 2^15); 1 for an all-zero tensor.
+// The exponent is clamped to [-100, 60]: beyond that the data are fp32 denormals / infinities and nothing is to be kept.
+__device__ __forceinline__ int x2_scale_exp(unsigned bits) {
+  const int e = (int)((bits >> 23) & 255);
+  int ex = e == 0 ? 0 : 141 - e;
+  ex = ex > 60 ? 60 : (ex < -100 ? -100 : ex);
+  return ex;
+}
+__device__ __forceinline__ float x2_pow2(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
+
+// STATS: the raw convolution output feeds a training-mode BatchNorm -- the kernel also produces, per channel and workgroup,
+// the partial statistics {K, n, sum (y - K), sum (y - K)^2} that dca_bn_finalize_centered consumes (bn_fused_stats.h), so the
+// 200 MB statistics pass over y disappears.  Per tile: 3 vector instructions per output value, a DPP reduction over the 32
+// positions of a wave half, one ds_add_f32 per (half, channel) into a wave-private LDS slot.
+template <bool VEC, bool STATS>
+__global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* b_lds = smem;
+  char* a_lds = smem + B_BYTES;
+  float* stat_lds = (float*)(smem + LDS_BYTES);     // STATS only (the launch adds STAT_LDS bytes)
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  const int cblk = blockIdx.y;
+  // persistent: the tile space (w fastest) is cut into one contiguous range per XCD (workgroups are dealt round-robin
+  // over the 8 XCDs, each with its own L2); inside its XCD's range, workgroup j of cnt takes tiles j, j + cnt, ... so
+  // at any time the CUs of an XCD work on neighbouring tiles and share their halos in that L2.  The load / MFMA
+  // pipeline runs straight across tile boundaries.
+  const long T = (long)a.N * a.nTD * a.nTH * a.nTW;
+  const int nx = gridDim.x >= 8 ? 8 : 1, xcd = blockIdx.x % nx;
+  const int cnt = (gridDim.x - xcd + nx - 1) / nx;          // workgroups on this XCD
+  const int t_begin = (int)(T * xcd / nx) + blockIdx.x / nx, t_end = (int)(T * (xcd + 1) / nx), t_step = cnt;
+  float* stat_w = stat_lds + wv * FS_WAVE_FLOATS;   // this wave's slots
+  bool stat_first = true;
+  float y_am = 0.f;          // max |y| this lane has written (y_amax)
+  if constexpr (STATS) {
+    for (int i = tid; i < 8 * FS_WAVE_FLOATS; i += 512) stat_lds[i] = 0.f;
+    __syncthreads();
+  }
+  if (t_begin >= t_end) {
+    if constexpr (STATS) fs_flush(stat_lds, 8, tid, cblk * 32, a.Cout, a.stat_part, gridDim.x, blockIdx.x);
+    return;
+  }
+
+  // per-lane byte offset of the lane's voxel inside a term image, for its two column tiles
+  // ds_read_b128 is served in four NON-contiguous 16-lane groups ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...:
+  // MI355X_MICROARCH.md, LDS).  A column tile is two h-rows of 16 voxels; the second row starts IW*16 = 288 B = 32 B
+  // (mod 256) after the first, which put lanes 20-27 on the banks of lanes 12-15 (2-way conflict in every group: 39 % of
+  // this kernel's LDS cycles were SQ_LDS_BANK_CONFLICT).  Rotating the second row's w by -2 voxels makes the bank pattern of
+  // lanes 16-31 equal to that of a contiguous 1 KiB read: conflict free.  The epilogue uses the same lane -> w map.
+  const int wlane = (l31 & 16) ? (((l31 & 15) - 2) & 15) : (l31 & 15);
+  int boff[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int r = (wv * 2 + t) * 2 + (l31 >> 4), dl = r >> 3, hl = r & 7;
+    boff[t] = (half * NVOX + (dl * IH + hl) * IW + wlane) * 16;
+  }
+
+  const int cstride = a.D * a.H * a.W;
+  const long sample = (long)a.Cin * cstride;
+  const int P = a.NCH * 3;   // phases: (chunk, kd)
+  const long wbytes = (long)P * A_SLAB;
+  const __amdgpu_buffer_rsrc_t wr = dca_rsrc((const char*)a.wx + (long)cblk * wbytes, wbytes);
+  const int xexp = x2_scale_exp(__builtin_amdgcn_readfirstlane(*a.x_amax));
+  const float xs = x2_pow2(xexp);                        // operand scale
+  const float inv = x2_pow2(-xexp) * a.wtail[1];         // accumulator -> fp32 result
+
+#if X2_STAMP
+  unsigned long long* stamps = (unsigned long long*)a.res_post;
+  a.res_post = nullptr;
+  const bool stamp_on = blockIdx.x == 0 && blockIdx.y == 0 && wv == 0;
+  int stamp_k = 0;
+#endif
+  const bool has_aff = a.scale != nullptr, has_pre = a.res_pre != nullptr, has_post = a.res_post != nullptr;
+  float4 ra[KA];
+  auto load_A = [&](int p) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < KA; ++k) {
+      const int it = tid + 512 * k;
+      ra[k] = dca_bload4(wr, p * A_SLAB + it * 16, (int)(it < NA_ITEMS));
+    }
+  };
+  auto store_A = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < KA; ++k) {
+      const int it = tid + 512 * k;
+      if (it < NA_ITEMS) *(float4*)(a_lds + buf * A_SLAB + it * 16) = ra[k];
+    }
+  };
+
+  // Staging of a chunk's halo tile, global -> registers (load_B) -> split -> LDS (store_B).
+  //  VEC (W % 4 == 0, 16-byte aligned x): a thread owns one aligned quad of 4 voxels along W (8 x b128, one per
+  //  channel of its k half) and, for tid < 240, one of the two edge voxels of a row (8 x b32): 16 loads per thread.
+  //  Otherwise: 5 single-voxel items of 8 x b32.
+  float4 rq[VEC ? 8 : 1];
+  float re[VEC ? 8 : 1];
+  float rb[VEC ? 1 : KB][8];
+  int item_crd[VEC ? 2 : KB];  // packed halo coordinates of the thread's items, fixed for the whole kernel
+  if constexpr (VEC) {
+    {
+      const int row = tid >> 2, q = tid & 3, kh = row / (ID * IH), rem = row - kh * (ID * IH), id = rem / IH, ih = rem - id * IH;
+      item_crd[0] = (tid < NQUAD) ? (id | (ih << 8) | ((1 + 4 * q) << 16) | (kh << 24)) : -1;
+    }
+    {
+      const int row = tid >> 1, side = tid & 1, kh = row / (ID * IH), rem = row - kh * (ID * IH), id = rem / IH, ih = rem - id * IH;
+      item_crd[1] = (tid < NEDGE) ? (id | (ih << 8) | ((side ? IW - 1 : 0) << 16) | (kh << 24)) : -1;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      const int it = tid + 512 * k;
+      const int kh = it / NVOX, v = it - kh * NVOX;
+      const int id = v / (IH * IW), rem = v - id * (IH * IW), ih = rem / IW, iw = rem - ih * IW;
+      item_crd[k] = (it < NB_ITEMS) ? (id | (ih << 8) | (iw << 16) | (kh << 24)) : -1;
+    }
+  }
+  auto item_off = [&](int crd, int d0, int h0, int w0, int chunk, int& c0, int& okv) __attribute__((always_inline)) {
+    const int di = d0 - 1 + (crd & 255), hi = h0 - 1 + ((crd >> 8) & 255), wi = w0 - 1 + ((crd >> 16) & 255);
+    c0 = chunk * 16 + ((crd >> 24) & 1) * 8;
+    okv = (int)(crd >= 0) & (int)((unsigned)di < (unsigned)a.D) & (int)((unsigned)hi < (unsigned)a.H) &
+          (int)((unsigned)wi < (unsigned)a.W);
+    return (c0 * cstride + (di * a.H + hi) * a.W + wi) * 4;
+  };
+  auto load_B = [&](int n, int d0, int h0, int w0, int chunk) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t xr = dca_rsrc(a.x + (long)n * sample, sample * 4);
+    if constexpr (VEC) {
+      int c0, okv;
+      const int offq = item_off(item_crd[0], d0, h0, w0, chunk, c0, okv);  // a quad is inside W or outside as a whole
+#pragma unroll
+      for (int j = 0; j < 8; ++j) rq[j] = dca_bload4(xr, offq + j * cstride * 4, okv & (int)(c0 + j < a.Cin));
+      const int offe = item_off(item_crd[1], d0, h0, w0, chunk, c0, okv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) re[j] = dca_bload1(xr, offe + j * cstride * 4, okv & (int)(c0 + j < a.Cin));
+    } else {
+#pragma unroll
+      for (int k = 0; k < KB; ++k) {
+        int c0, okv;
+        const int off = item_off(item_crd[k], d0, h0, w0, chunk, c0, okv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rb[k][j] = dca_bload1(xr, off + j * cstride * 4, okv & (int)(c0 + j < a.Cin));
+      }
+    }
+  };
+  auto split_store = [&](const float (&v)[8], int vox_off) __attribute__((always_inline)) {
+    f16x8 hv, lv;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      _Float16 h, l;
+      split2(v[j], xs, h, l);
+      hv[j] = h; lv[j] = l;
+    }
+    *(f16x8*)(b_lds + vox_off) = hv;
+    *(f16x8*)(b_lds + B_TERM + vox_off) = lv;
+  };
+  auto crd_lds = [&](int crd) __attribute__((always_inline)) {  // byte offset of the item's (first) voxel in a term image
+    return ((((crd >> 24) & 1) * ID + (crd & 255)) * IH + ((crd >> 8) & 255)) * IW * 16 + ((crd >> 16) & 255) * 16;
+  };
+  auto store_B = [&]() __attribute__((always_inline)) {
+    if constexpr (VEC) {
+      if (item_crd[0] >= 0) {
+        const int o = crd_lds(item_crd[0]);
+        const float v0[8] = {rq[0].x, rq[1].x, rq[2].x, rq[3].x, rq[4].x, rq[5].x, rq[6].x, rq[7].x};
+        const float v1[8] = {rq[0].y, rq[1].y, rq[2].y, rq[3].y, rq[4].y, rq[5].y, rq[6].y, rq[7].y};
+        const float v2[8] = {rq[0].z, rq[1].z, rq[2].z, rq[3].z, rq[4].z, rq[5].z, rq[6].z, rq[7].z};
+        const float v3[8] = {rq[0].w, rq[1].w, rq[2].w, rq[3].w, rq[4].w, rq[5].w, rq[6].w, rq[7].w};
+        split_store(v0, o); split_store(v1, o + 16); split_store(v2, o + 32); split_store(v3, o + 48);
+      }
+      if (item_crd[1] >= 0) {
+        const float v[8] = {re[0], re[1], re[2], re[3], re[4], re[5], re[6], re[7]};
+        split_store(v, crd_lds(item_crd[1]));
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < KB; ++k)
+        if (item_crd[k] >= 0) split_store(rb[k], crd_lds(item_crd[k]));
+    }
+  };
+  auto decode = [&](int tile, int& n, int& d0, int& h0, int& w0) __attribute__((always_inline)) {
+    const int tw = tile % a.nTW; tile /= a.nTW;
+    const int th = tile % a.nTH; tile /= a.nTH;
+    const int td = tile % a.nTD;
+    n = tile / a.nTD;
+    d0 = td * TD; h0 = th * TH; w0 = tw * TW;
+  };
+
+  int n, d0, h0, w0;
+  decode(t_begin, n, d0, h0, w0);
+  load_B(n, d0, h0, w0, 0);
+  load_A(0);
+  store_B();
+  store_A(0);
+  load_A(1);   // P >= 3
+  __syncthreads();
+
+  int buf = 0;  // A slab buffer of the current phase (phases alternate buffers across chunk and tile boundaries)
+#pragma unroll 1
+  for (int tile = t_begin; tile < t_end; tile += t_step) {
+    const bool more_tiles = tile + t_step < t_end;
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    int nn = n, nd0 = d0, nh0 = h0, nw0 = w0;  // coordinates of the next tile (valid when more_tiles)
+
+#pragma unroll 1
+    for (int p = 0; p < P; ++p, buf ^= 1) {
+      const int chunk = p / 3, kd = p - chunk * 3;
+      const bool last_of_chunk = kd == 2;
+      const bool next_chunk = last_of_chunk && (chunk + 1 < a.NCH);
+      const bool next_tile = last_of_chunk && !next_chunk && more_tiles;
+      X2_MARK(0);
+      // slab p+1 (in registers since the previous phase) -> the buffer phase p-1 used; then fetch slab p+2
+      if (p + 1 < P || more_tiles) store_A(buf ^ 1);
+      if (p + 2 < P || more_tiles) load_A(p + 2 < P ? p + 2 : p + 2 - P);
+      if (next_tile) decode(tile + t_step, nn, nd0, nh0, nw0);
+      const bool stage = next_chunk || next_tile;  // fetch the halo tile of the next chunk / chunk 0 of the next tile
+      const char* ab = a_lds + buf * A_SLAB + lane * 16;
+      const char* bb = b_lds + kd * (IH * IW * 16);
+      // The 9 taps of the slab with a register double buffer: the 9 ds_read_b128 of tap+1 go one per MFMA between
+      // the 12 MFMAs of tap, and in a staging phase the global loads of the next halo tile are spread over the taps
+      // as well (all issued up front they fill the CU's memory queue and the waves sit in the issue stage for
+      // microseconds with the matrix pipe idle).  sched_group_barrier pins the order; left alone, hipcc issues each
+      // LDS read right before its first use and waits on it.
+      auto phase = [&](auto STAGE) __attribute__((always_inline)) {
+        constexpr bool ST = decltype(STAGE)::value;
+        constexpr int NLD = VEC ? 2 : 5;  // global loads per tap (8 taps): 16 / 40 per thread
+        if constexpr (ST) {
+          const bool nt = next_tile;
+          load_B(nt ? nn : n, nt ? nd0 : d0, nt ? nh0 : h0, nt ? nw0 : w0, nt ? 0 : chunk + 1);
+        }
+        f16x8 fa[2][NT], fb[2][2][NT];
+        auto load_frag = [&](int tap9, int slot) __attribute__((always_inline)) {
+          const int kh = tap9 / 3, kw = tap9 - kh * 3;
+#pragma unroll
+          for (int term = 0; term < NT; ++term) fa[slot][term] = *(const f16x8*)(ab + (tap9 * NT + term) * 1024);
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int term = 0; term < NT; ++term)
+              fb[slot][t][term] = *(const f16x8*)(bb + boff[t] + (kh * IW + kw) * 16 + term * B_TERM);
+        };
+        load_frag(0, 0);
+#pragma unroll
+        for (int tap9 = 0; tap9 < 9; ++tap9) {
+          const int cur = tap9 & 1;
+          if (tap9 < 8) load_frag(tap9 + 1, cur ^ 1);
+          // smallest terms first; the two column tiles alternate so consecutive MFMAs never chain on one accumulator
+          constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][PA[q]], fb[cur][t][PB[q]], acc[t], 0, 0, 0);
+          if (tap9 < 8) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              if (ST && i < NLD) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+          }
+        }
+      };
+      X2_MARK(1);
+      if (stage) phase(std::true_type{}); else phase(std::false_type{});
+      X2_MARK(2);
+      if (stage) {
+        __syncthreads();  // every wave is done reading the halo tile of this chunk
+        X2_MARK(3);
+        store_B();
+        X2_MARK(4);
+      }
+      __syncthreads();
+      X2_MARK(5);
+#if X2_STAMP
+      if (p + 1 < P) ++stamp_k;
+#endif
+    }
+    X2_MARK(6);
+
+    // Epilogue (same contract as conv3d_mfma.hip): y = act(acc * scale + shift + res_pre) + res_post.  The stores
+    // drain while the next tile's first phase runs.
+    // 32-bit offsets into this sample's output through buffer descriptors: nothing 64-bit for the compiler to hoist
+    // out of the tile loop (that cost ~60 spilled registers), and the bounds masks ride on the hardware range check.
+    const long osample = (long)a.Cout * cstride;
+    const __amdgpu_buffer_rsrc_t yr = dca_rsrc(a.y + (long)n * osample, osample * 4);
+    const __amdgpu_buffer_rsrc_t pr = dca_rsrc((has_pre ? a.res_pre : a.y) + (long)n * osample, osample * 4);
+    const __amdgpu_buffer_rsrc_t qr = dca_rsrc((has_post ? a.res_post : a.y) + (long)n * osample, osample * 4);
+    float sc[16], sh[16];  // (re)loaded per tile: holding them across the MFMA phases costs 32 registers
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = min(cblk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, a.Cout - 1);
+      sc[r] = (has_aff ? a.scale[co] : 1.f) * inv;
+      sh[r] = has_aff ? a.shift[co] : 0.f;
+    }
+    float st_s[STATS ? 16 : 1], st_q[STATS ? 16 : 1], st_n = 0.f;
+    if constexpr (STATS) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st_s[r] = st_q[r] = 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int r0 = (wv * 2 + t) * 2 + (l31 >> 4), d = d0 + (r0 >> 3), h = h0 + (r0 & 7), w = w0 + wlane;
+      const int ok = (int)(d < a.D) & (int)(h < a.H) & (int)(w < a.W);
+      if constexpr (STATS) st_n += (float)ok;
+      const int voff = ((d * a.H + h) * a.W + w + (cblk * 32 + 4 * half) * cstride) * 4;
+      float rp[16], rq[16];
+      if (has_pre) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int cu = (r & 3) + 8 * (r >> 2);
+          rp[r] = dca_bload1(pr, voff + cu * cstride * 4, ok & (int)(cblk * 32 + cu + 4 * half < a.Cout));
+        }
+      }
+      if (has_post) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int cu = (r & 3) + 8 * (r >> 2);
+          rq[r] = dca_bload1(qr, voff + cu * cstride * 4, ok & (int)(cblk * 32 + cu + 4 * half < a.Cout));
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cu = (r & 3) + 8 * (r >> 2);
+        float v = acc[t][r] * sc[r] + sh[r];
+        if (has_pre) v += rp[r];
+        v = act_apply(v, a.slope);
+        if (has_post) v += rq[r];
+        if constexpr (STATS) {
+          if (stat_first && t == 0) {   // the wave's first tile: the shift of (half, r) = what lane 0 of the half produced
+            const float kf = fs_half_first(v, half);
+            if ((lane & 31) == 0) fs_slot(stat_w, half, r)[0] = kf;
+          }
+          const float dlt = ok ? v - fs_slot(stat_w, half, r)[0] : 0.f;
+          st_s[r] += dlt;
+          st_q[r] = fmaf(dlt, dlt, st_q[r]);
+        }
+        const int okc = ok & (int)(cblk * 32 + cu + 4 * half < a.Cout);
+        y_am = fmaxf(y_am, okc ? fabsf(v) : 0.f);
+#if X2_NT
+        dca_bstore1_nt(yr, v, voff + cu * cstride * 4, okc);
+#else
+        dca_bstore1(yr, v, voff + cu * cstride * 4, okc);
+#endif
+      }
+    }
+    if constexpr (STATS) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float rs = fs_half_sum(st_s[r]), rq2 = fs_half_sum(st_q[r]);
+        if ((lane & 31) == 0) {
+          atomicAdd(fs_slot(stat_w, half, r) + 1, rs);    // ds_add_f32 without return; wave-private slot, one writer lane
+          atomicAdd(fs_slot(stat_w, half, r) + 2, rq2);
+        }
+      }
+      const float rn = fs_half_sum(st_n);
+      if ((lane & 31) == 0) atomicAdd(stat_w + 96 + half, rn);
+      stat_first = false;
+    }
+    X2_MARK(7);
+#if X2_STAMP
+    ++stamp_k;
+#endif
+    n = nn; d0 = nd0; h0 = nh0; w0 = nw0;
+  }
+  if constexpr (STATS) {
+    __syncthreads();
+    fs_flush(stat_lds, 8, tid, cblk * 32, a.Cout, a.stat_part, gridDim.x, blockIdx.x);
+  }
+  if (a.y_amax) {   // the consumer's operand maximum, for the next f16x2 convolution (order-independent atomicMax)
+    y_am = wave_max(y_am);
+    if (lane == 0 && y_am > 0.f) atomicMax(a.y_amax, __float_as_uint(y_am));
+  }
+}
+
+// Weight packing.  Stage 1 (one workgroup): max |w| of the tensor -> {2^ew, 2^-ew} behind the packed image (ew brings the
+// maximum into [2^14, 2^15)).  Stage 2: wx[cblk][chunk][tap][term][lane][j] (f16): lane (r = lane & 31, h = lane >> 5)
+// holds A[row = output channel cblk*32 + r][k = input channel chunk*16 + 8h + j] of the tap, scaled by 2^ew and split into
+// term 0/1 = h/l; zero padded.  Source indexing as dca_conv3d_prep_weight: src_ab ? src[a][b][27] : src[b][a][27]; flip
+// reverses the tap order.
+__global__ __launch_bounds__(1024) void x2_weight_scale_kernel(const float* __restrict__ src, long count,
+                                                               float* __restrict__ tail) {
+  float m = 0.f;
+  for (long i = threadIdx.x; i < count; i += 1024) m = fmaxf(m, fabsf(src[i]));
+  m = wave_max(m);
+  __shared__ float red[16];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
+    const int ew = x2_scale_exp(__float_as_uint(m));
+    tail[0] = x2_pow2(ew);
+    tail[1] = x2_pow2(-ew);
+    tail[2] = m;
+    tail[3] = 0.f;
+  }
+}
+
+__global__ void x2_prep_weight_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int A, int Bn,
+                                      int NCH, int src_ab, int flip, long total) {
+  const float ws = ((const float*)(dst + total))[0];
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int j = idx & 7, lane = (idx >> 3) & 63;
+    long t = idx >> 9;
+    const int term = t % NT; t /= NT;
+    const int tap = t % 27; t /= 27;
+    const int chunk = t % NCH;
+    const int cblk = (int)(t / NCH);
+    const int bi = cblk * 32 + (lane & 31), ai = chunk * 16 + 8 * (lane >> 5) + j;
+    float v = 0.f;
+    if (ai < A && bi < Bn) {
+      const int st = flip ? 26 - tap : tap;
+      v = src_ab ? src[((long)ai * Bn + bi) * 27 + st] : src[((long)bi * A + ai) * 27 + st];
+    }
+    _Float16 h, l;
+    split2(v, ws, h, l);
+    dst[idx] = __builtin_bit_cast(unsigned short, term == 0 ? h : l);
+  }
+}
+
+// max |x| over a tensor as the bit pattern of an fp32 number: atomicMax on the unsigned patterns of |x| (monotonic for
+// non-negative floats) is order independent, so the result is bitwise reproducible.  The word must be zero beforehand.
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long n, int vec, unsigned* __restrict__ out) {
+  float m = 0.f;
+  const long stride = (long)gridDim.x * 256;
+  if (vec) {
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+      const float4 v = ((const float4*)x)[i];
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) m = fmaxf(m, fabsf(x[i]));
+  } else {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) m = fmaxf(m, fabsf(x[i]));
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+
+}  // namespace
+
+// word <- bit pattern of max |x[0..n)| (fp32): the operand maximum the f16x2 kernels scale by.  Two stream operations
+// (a 4-byte memset and one read pass); producers that know their output's maximum write the word themselves
+// (dca_bn_apply_amax, dca_bn_backward_amax).
+extern "C" int dca_amax_f32(const float* x, long n, unsigned* word, hipStream_t stream) {
+  DCA_REQUIRE(x && word && n > 0);
+  hipError_t e = hipMemsetAsync(word, 0, 4, stream);
+  if (e != hipSuccess) return (int)e;
+  const int vec = (((uintptr_t)x) & 15) == 0;
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(amax_kernel, dim3((int)blocks), dim3(256), 0, stream, x, n, vec, word);
+  return dca_launch_status();
+}
+
+// bytes of the packed image: fragments, then 16 bytes {2^ew, 2^-ew, max |w|, 0}
+extern "C" long dca_conv3d_x2_weight_bytes(int Cin, int Cout) {
+  if (Cin <= 0 || Cout <= 0) return 0;
+  return (long)((Cout + 31) / 32) * ((Cin + 15) / 16) * 27 * NT * 1024 + 16;
+}
+
+extern "C" int dca_conv3d_x2_prep_weight(const float* w, void* wx, int A, int B, int src_ab, int flip,
+                                         hipStream_t stream) {
+  DCA_REQUIRE(w && wx && A > 0 && B > 0 && ((((uintptr_t)wx) & 15) == 0));
+  const int NCH = (A + 15) / 16;
+  const long total = (dca_conv3d_x2_weight_bytes(A, B) - 16) / 2;
+  hipLaunchKernelGGL(x2_weight_scale_kernel, dim3(1), dim3(1024), 0, stream, w, (long)A * B * 27,
+                     (float*)((unsigned short*)wx + total));
+  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(x2_prep_weight_kernel, dim3(grid), dim3(256), 0, stream, w, (unsigned short*)wx, A, B, NCH, src_ab,
+                     flip, total);
+  return dca_launch_status();
+}
+
+namespace {
+
+int x2_grid(long tiles, int cblks) {
+  // persistent: one workgroup per CU, each looping over its share of the tiles
+  int ncu = 256;   // per device, so not cached in a static
+  {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      ncu = v;
+  }
+  int gx = ncu / cblks > 0 ? ncu / cblks : 1;
+  if (gx > tiles) gx = (int)tiles;
+  return gx;
+}
+
+int x2_launch(const float* x, const unsigned* x_amax, const void* wx, float* y, const float* scale, const float* shift,
+              const float* res_pre, const float* res_post, float slope, double* stat_part, unsigned* y_amax, int N,
+              int Cin, int Cout, int D, int H, int W, hipStream_t stream) {
+  DCA_REQUIRE(x && x_amax && wx && y && N > 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0);
+  DCA_REQUIRE((scale == nullptr) == (shift == nullptr));
+  DCA_REQUIRE((long)Cin * D * H * W * 4 < 0x7ffffff0L && (long)Cout * D * H * W * 4 < 0x7ffffff0L);  // 32-bit byte offsets inside one sample
+  DCA_REQUIRE((((uintptr_t)wx) & 15) == 0 && (((uintptr_t)x_amax) & 3) == 0);
+  X2Args a;
+  a.x = x; a.wx = (const unsigned short*)wx; a.y = y;
+  a.scale = scale; a.shift = shift; a.res_pre = res_pre; a.res_post = res_post; a.slope = slope;
+  a.N = N; a.Cin = Cin; a.Cout = Cout; a.NCH = (Cin + 15) / 16;
+  a.D = D; a.H = H; a.W = W;
+  a.nTD = cdiv(D, TD); a.nTH = cdiv(H, TH); a.nTW = cdiv(W, TW);
+  a.stat_part = stat_part;
+  a.x_amax = x_amax;
+  a.y_amax = y_amax;
+  a.wtail = (const float*)((const char*)wx + dca_conv3d_x2_weight_bytes(Cin, Cout) - 16);
+  const long tiles = (long)N * a.nTD * a.nTH * a.nTW;
+  DCA_REQUIRE(tiles < 0x7fffffffL && (Cout + 31) / 32 <= 65535);
+  const bool vec = (W % 4 == 0) && ((((uintptr_t)x) & 15) == 0);
+  const bool stats = stat_part != nullptr;
+  auto kern = stats ? (vec ? conv3_f16x2_kernel<true, true> : conv3_f16x2_kernel<false, true>)
+                    : (vec ? conv3_f16x2_kernel<true, false> : conv3_f16x2_kernel<false, false>);
+  const int lds = LDS_BYTES + (stats ? STAT_LDS : 0);
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) return (int)e;
+  const int cblks = (Cout + 31) / 32;
+  hipLaunchKernelGGL(kern, dim3(x2_grid(tiles, cblks), cblks), dim3(512), lds, stream, a);
+  return dca_launch_status();
+}
+
+}  // namespace
+
+// y = act(conv(x, w) * scale[c] + shift[c] + res_pre) + res_post (the epilogue contract of dca_conv3d_forward) with the
+// f16x2 split arithmetic; x_amax = device word holding the bit pattern of max |x| (dca_amax_f32 or a producer); y_amax
+// (may be null) = zero-initialised device word that receives the bit pattern of max |y| for the consumer of y.
+extern "C" int dca_conv3d_x2_forward(const float* x, const unsigned* x_amax, const void* wx, float* y, const float* scale,
+                                     const float* shift, const float* res_pre, const float* res_post, float slope,
+                                     unsigned* y_amax, int N, int Cin, int Cout, int D, int H, int W, hipStream_t stream) {
+  return x2_launch(x, x_amax, wx, y, scale, shift, res_pre, res_post, slope, nullptr, y_amax, N, Cin, Cout, D, H, W,
+                   stream);
+}
+
+// nchunk of the statistics dca_conv3d_x2_forward_stats produces (one partial per workgroup of the launch it will make)
+extern "C" long dca_conv3d_x2_stats_chunks(int N, int Cout, int D, int H, int W) {
+  if (N <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+  const long tiles = (long)N * cdiv(D, TD) * cdiv(H, TH) * cdiv(W, TW);
+  return x2_grid(tiles, (Cout + 31) / 32);
+}
+
+// y = conv(x, w) (no epilogue) plus the BatchNorm batch statistics of y: part (Cout * nchunk * 4 doubles, nchunk =
+// dca_conv3d_x2_stats_chunks) = one {K, n, sum (y - K), sum (y - K)^2} per (channel, workgroup), for
+// dca_bn_finalize_centered (bn_fused_stats.h)
+extern "C" int dca_conv3d_x2_forward_stats(const float* x, const unsigned* x_amax, const void* wx, float* y,
+                                           double* stat_part, int N, int Cin, int Cout, int D, int H, int W,
+                                           hipStream_t stream) {
+  DCA_REQUIRE(stat_part);
+  return x2_launch(x, x_amax, wx, y, nullptr, nullptr, nullptr, nullptr, 1.f, stat_part, nullptr, N, Cin, Cout, D, H, W,
+                   stream);
+}

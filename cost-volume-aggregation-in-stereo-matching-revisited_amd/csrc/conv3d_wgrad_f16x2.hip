@@ -1,0 +1,355 @@
+// Weight gradient of the 3x3x3 stride-1 convolution on the f16 matrix pipe with fp32-grade accuracy (the "f16x2" split of
+// conv3d_f16x2.hip: both operands scaled by a power of two taken from their tensor's max |.|, split into two f16 terms,
+// the three partial products >= 2^-11 accumulated in fp32; the slab written at the end is scaled back).
+//
+//   dW[co][ci][kd,kh,kw] = sum_{n,d,h,w} dy[n][co][d][h][w] * x[n][ci][d+kd-1][h+kh-1][w+kw-1]
+//
+// is, per tap, a 32 x 32 (co x ci) matrix contracted over the voxels: one v_mfma_f32_32x32x16_f16 takes 16 voxels
+// (one W row segment of the tile) as K.  A lane's operand fragment is 8 consecutive voxels of one channel, which is
+// contiguous in NCDHW -- so the LDS images are [term][row][k half][channel][8 voxels] and every fragment is one
+// ds_read_b128.  The kw = -1 / +1 taps need the same 8 voxels shifted by one element: rather than unaligned LDS reads
+// the lane takes its aligned group G, one neighbour dword from its partner lane (v_permlane32_swap: the two k halves
+// of a row sit in lanes l and l+32) or from a 2-element edge image, and builds both shifted fragments with five
+// v_alignbit_b32 per term.  (Structure of conv3d_wgrad_bf16x3.hip with two terms instead of three.)
+//
+// Reference operator served: the weight gradient autograd computes for nn.Conv3d(k=3, s=1, p=1) of convbn_3d
+// (models/submodule.py:121-124) and the cva blocks (models/augment/cva.py:13-55).
+//
+// Work decomposition: persistent workgroups of 8 waves (one per CU).  A tile is 2 x 4 x 16 output voxels = 8 K-steps;
+// the 8 waves are two groups of four, each group takes 4 K-steps, and inside a group the 27 taps are split 7/7/7/6 over
+// the waves (7 x 16 accumulator registers per lane).  The next tile's x halo rows and dy rows are fetched into registers
+// during the MFMA phase, split and written to LDS between two barriers.  At the end the two groups are summed through
+// LDS and the workgroup writes one slab of partial sums; wgrad_reduce_kernel (conv3d_wgrad.hip) adds the slabs in a
+// fixed order: bitwise reproducible, no atomics.
+#include "dca_common.h"
+#include <type_traits>
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+
+int dca_internal_wgrad_reduce(const float* part, float* dw, int nblk, int nCxT, int nCT, int K, int Cy, int Cx,
+                              long s_cy, long s_cx, hipStream_t stream);  // conv3d_wgrad.hip
+
+// WX2_STAMP (debug build, tools/wx3_stamps.py): `part` is followed by an unsigned long long stamp buffer (the tool
+// allocates it) that receives s_memtime stamps of the first 64 tiles of workgroup 0, waves 0 and 3
+#ifndef WX2_STAMP
+#define WX2_STAMP 0
+#endif
+#ifndef WX2_LOADS_IN
+#define WX2_LOADS_IN 1
+#endif
+#if WX2_STAMP
+#define WX2_MARK(i) do { if (stamp_on && stamp_k < 64) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) stamps[((wq == 3) * 64 + stamp_k) * 8 + (i)] = t_; } } while (0)
+#else
+#define WX2_MARK(i) do { } while (0)
+#endif
+
+namespace {
+
+constexpr int NT = 2;                                 // terms per operand
+constexpr int TD = 2, TH = 4, TW = 16;
+constexpr int NROW = TD * TH;                       // 8 K-steps (output rows) per tile
+constexpr int HD = TD + 2, HH = TH + 2, NHROW = HD * HH;  // 24 halo rows
+constexpr int X_TERM = NHROW * 2 * 32 * 16;         // bytes of one term image of x: [hrow][k half][ci][8 f16]
+constexpr int XE_TERM = NHROW * 2 * 32 * 4;         // edge dwords: [hrow][side][ci]
+constexpr int Y_TERM = NROW * 2 * 32 * 16;
+constexpr int X_OFF = 0, XE_OFF = NT * X_TERM, Y_OFF = XE_OFF + NT * XE_TERM;
+constexpr int LDS_BYTES_T = Y_OFF + NT * Y_TERM;    // 49152 + 12288 + 16384 = 77824
+constexpr int LDS_BYTES = LDS_BYTES_T > 4 * 7 * 4096 ? LDS_BYTES_T : 4 * 7 * 4096;   // the end-of-kernel reduction reuses the LDS (114688)
+constexpr int NX_ITEMS = NHROW * 2 * 32, KX = NX_ITEMS / 512;    // 1536 -> 3 per thread (8 floats each)
+constexpr int NE_ITEMS = NHROW * 2 * 32, KE = NE_ITEMS / 512;    // 1536 -> 3 scalars per thread
+constexpr int NY_ITEMS = NROW * 2 * 32, KY = NY_ITEMS / 512;     // 512  -> 1 per thread
+static_assert(NX_ITEMS % 512 == 0 && NY_ITEMS % 512 == 0, "staging items");
+
+struct WX2Args {
+  const float* x;
+  const float* dy;
+  float* part;
+  int N, Cx, Cy, D, H, W;
+  int nTD, nTH, nTW, nCxT;
+  const unsigned* x_amax;   // bit patterns of max |x| / max |dy| (fp32), device words
+  const unsigned* y_amax;
+};
+
+__device__ __forceinline__ void split2(float v, float s, _Float16& h, _Float16& l) {
+  const float u = v * s;          // exact: power of two, scaled maximum < 2^15
+  h = (_Float16)u;
+  l = (_Float16)(u - (float)h);   // the residual is exact in fp32
+}
+// as in conv3d_f16x2.hip
+__device__ __forceinline__ int x2_scale_exp(unsigned bits) {
+  const int e = (int)((bits >> 23) & 255);
+  int ex = e == 0 ? 0 : 141 - e;
+  ex = ex > 60 ? 60 : (ex < -100 ? -100 : ex);
+  return ex;
+}
+__device__ __forceinline__ float x2_pow2(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
+
+__global__ __launch_bounds__(512) void wgrad3_f16x2_kernel(WX2Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  const int grp = wv >> 2, wq = wv & 3;
+  const int ct = blockIdx.y, cy0 = (ct / a.nCxT) * 32, cx0 = (ct % a.nCxT) * 32;
+
+  const long T = (long)a.N * a.nTD * a.nTH * a.nTW;
+  const int nx = gridDim.x >= 8 ? 8 : 1, xcd = blockIdx.x % nx;
+  const int cnt = (gridDim.x - xcd + nx - 1) / nx;
+  const int t_begin = (int)(T * xcd / nx) + blockIdx.x / nx, t_end = (int)(T * (xcd + 1) / nx), t_step = cnt;
+
+  f32x16 acc[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const int cstride = a.D * a.H * a.W;
+  const long xsample = (long)a.Cx * cstride, ysample = (long)a.Cy * cstride;
+  const int xexp = x2_scale_exp(__builtin_amdgcn_readfirstlane(*a.x_amax));
+  const int yexp = x2_scale_exp(__builtin_amdgcn_readfirstlane(*a.y_amax));
+  const float xs = x2_pow2(xexp), ys = x2_pow2(yexp);
+
+  // staging items: channel fastest (conflict-free LDS writes), then k half / side, then row
+  float4 rx[KX][2], ry[KY][2];
+  float re[KE];
+  auto decode = [&](int tile, int& n, int& d0, int& h0, int& w0) __attribute__((always_inline)) {
+    const int tw = tile % a.nTW; tile /= a.nTW;
+    const int th = tile % a.nTH; tile /= a.nTH;
+    const int td = tile % a.nTD;
+    n = tile / a.nTD;
+    d0 = td * TD; h0 = th * TH; w0 = tw * TW;
+  };
+  auto load_tile = [&](int n, int d0, int h0, int w0) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t xr = dca_rsrc(a.x + (long)n * xsample, xsample * 4);
+    const __amdgpu_buffer_rsrc_t yr = dca_rsrc(a.dy + (long)n * ysample, ysample * 4);
+#pragma unroll
+    for (int k = 0; k < KX; ++k) {
+      const int it = tid + 512 * k, c = it & 31, hf = (it >> 5) & 1, hrow = it >> 6;
+      const int d = d0 - 1 + hrow / HH, h = h0 - 1 + hrow % HH, w = w0 + 8 * hf;
+      const int ok = (int)(cx0 + c < a.Cx) & (int)((unsigned)d < (unsigned)a.D) & (int)((unsigned)h < (unsigned)a.H);
+      const int off = ((cx0 + c) * cstride + (d * a.H + h) * a.W + w) * 4;
+      rx[k][0] = dca_bload4(xr, off, ok & (int)(w + 3 < a.W));       // W % 4 == 0: a quad is inside or outside
+      rx[k][1] = dca_bload4(xr, off + 16, ok & (int)(w + 7 < a.W));
+    }
+#pragma unroll
+    for (int k = 0; k < KE; ++k) {
+      const int it = tid + 512 * k, c = it & 31, side = (it >> 5) & 1, hrow = it >> 6;
+      const int d = d0 - 1 + hrow / HH, h = h0 - 1 + hrow % HH, w = side ? w0 + TW : w0 - 1;
+      const int ok = (int)(cx0 + c < a.Cx) & (int)((unsigned)d < (unsigned)a.D) & (int)((unsigned)h < (unsigned)a.H) &
+                     (int)((unsigned)w < (unsigned)a.W);
+      re[k] = dca_bload1(xr, ((cx0 + c) * cstride + (d * a.H + h) * a.W + w) * 4, ok);
+    }
+#pragma unroll
+    for (int k = 0; k < KY; ++k) {
+      const int it = tid + 512 * k, c = it & 31, hf = (it >> 5) & 1, row = it >> 6;
+      const int d = d0 + row / TH, h = h0 + row % TH, w = w0 + 8 * hf;
+      const int ok = (int)(cy0 + c < a.Cy) & (int)(d < a.D) & (int)(h < a.H);
+      const int off = ((cy0 + c) * cstride + (d * a.H + h) * a.W + w) * 4;
+      ry[k][0] = dca_bload4(yr, off, ok & (int)(w + 3 < a.W));
+      ry[k][1] = dca_bload4(yr, off + 16, ok & (int)(w + 7 < a.W));
+    }
+  };
+  auto split_store8 = [&](const float4& p, const float4& q, float sc, char* base, int term_stride, int off) __attribute__((always_inline)) {
+    const float v[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
+    f16x8 hv, lv;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      _Float16 h, l;
+      split2(v[j], sc, h, l);
+      hv[j] = h; lv[j] = l;
+    }
+    *(f16x8*)(base + off) = hv;
+    *(f16x8*)(base + term_stride + off) = lv;
+  };
+  auto store_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < KX; ++k) split_store8(rx[k][0], rx[k][1], xs, smem + X_OFF, X_TERM, (tid + 512 * k) * 16);
+#pragma unroll
+    for (int k = 0; k < KY; ++k) split_store8(ry[k][0], ry[k][1], ys, smem + Y_OFF, Y_TERM, (tid + 512 * k) * 16);
+#pragma unroll
+    for (int k = 0; k < KE; ++k) {
+      const int it = tid + 512 * k, side = (it >> 5) & 1;
+      _Float16 h, l;
+      split2(re[k], xs, h, l);
+      // left edge (side 0) sits in the HIGH half of its dword, right edge (side 1) in the LOW half (see shifts below)
+      const unsigned sh = side ? 0 : 16;
+      *(unsigned*)(smem + XE_OFF + it * 4) = (unsigned)__builtin_bit_cast(unsigned short, h) << sh;
+      *(unsigned*)(smem + XE_OFF + XE_TERM + it * 4) = (unsigned)__builtin_bit_cast(unsigned short, l) << sh;
+    }
+  };
+
+  // The MFMA phase of one tile for tap group WQ (taps 7*WQ .. 7*WQ+6, < 27).  The next tile's global loads are issued
+  // BEHIND the first K-step's MFMAs: in front of the phase the address arithmetic and the memory pipe's back-pressure of
+  // 11 load instructions per thread kept all eight waves -- and the matrix pipe -- busy for 1600-1900 of a tile's 18.9 k
+  // cycles (s_memtime stamps, tools/wx3_stamps.py).
+  auto mfma_tile = [&](auto WQC, bool more, int next_tile) __attribute__((always_inline)) {
+    constexpr int WQ = decltype(WQC)::value;
+    constexpr int TAP0 = 7 * WQ, TAP1 = (TAP0 + 7 < 27) ? TAP0 + 7 : 27;
+    constexpr int R0 = TAP0 / 3, R1 = (TAP1 - 1) / 3;  // (kd, kh) rows this wave touches
+#pragma unroll 1
+    for (int i = 0; i < NROW / 2; ++i) {
+      if (WX2_LOADS_IN && i == 1 && more) {
+        int nn, nd0, nh0, nw0;
+        decode(next_tile, nn, nd0, nh0, nw0);
+        load_tile(nn, nd0, nh0, nw0);
+      }
+      const int row = grp * (NROW / 2) + i, dl = row / TH, hl = row % TH;
+      f16x8 ay[NT];
+#pragma unroll
+      for (int term = 0; term < NT; ++term)
+        ay[term] = *(const f16x8*)(smem + Y_OFF + term * Y_TERM + ((row * 2 + half) * 32 + l31) * 16);
+#pragma unroll
+      for (int rr = R0; rr <= R1; ++rr) {
+        const int kd = rr / 3, kh = rr % 3;
+        const int hrow = (dl + kd) * HH + hl + kh;
+        u32x4v g[NT];
+        unsigned e[NT];
+#pragma unroll
+        for (int term = 0; term < NT; ++term) {
+          g[term] = *(const u32x4v*)(smem + X_OFF + term * X_TERM + ((hrow * 2 + half) * 32 + l31) * 16);
+          e[term] = *(const unsigned*)(smem + XE_OFF + term * XE_TERM + ((hrow * 2 + half) * 32 + l31) * 4);
+        }
+        // fragments for kw = 0 (g itself), kw = -1 (s[0..3]) and kw = +1 (s[1..4])
+        u32x4v fm[NT], fp[NT];
+#pragma unroll
+        for (int term = 0; term < NT; ++term) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(g[term][0], g[term][3], false, false);
+          const unsigned ld = half ? sw[0] : e[term];   // dword whose HIGH half is the voxel left of g[0]
+          const unsigned rd = half ? e[term] : sw[1];   // dword whose LOW half is the voxel right of g[7]
+          const unsigned s0 = __builtin_amdgcn_alignbit(g[term][0], ld, 16);
+          const unsigned s1 = __builtin_amdgcn_alignbit(g[term][1], g[term][0], 16);
+          const unsigned s2 = __builtin_amdgcn_alignbit(g[term][2], g[term][1], 16);
+          const unsigned s3 = __builtin_amdgcn_alignbit(g[term][3], g[term][2], 16);
+          const unsigned s4 = __builtin_amdgcn_alignbit(rd, g[term][3], 16);
+          fm[term] = (u32x4v){s0, s1, s2, s3};
+          fp[term] = (u32x4v){s1, s2, s3, s4};
+        }
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int tap = rr * 3 + kw;
+          if (tap < TAP0 || tap >= TAP1) continue;
+          const int j = tap - TAP0;
+          f16x8 bx[NT];
+#pragma unroll
+          for (int term = 0; term < NT; ++term)
+            bx[term] = __builtin_bit_cast(f16x8, kw == 0 ? fm[term] : (kw == 1 ? g[term] : fp[term]));
+          // smallest terms first
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ay[0], bx[1], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ay[1], bx[0], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ay[0], bx[0], acc[j], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+#if WX2_STAMP
+  unsigned long long* stamps = (unsigned long long*)(a.part + (long)gridDim.x * gridDim.y * 27 * 1024);
+  const bool stamp_on = blockIdx.x == 0 && blockIdx.y == 0 && grp == 0 && (wq == 0 || wq == 3);
+  int stamp_k = 0;
+#endif
+  if (t_begin < t_end) {
+    int n, d0, h0, w0;
+    decode(t_begin, n, d0, h0, w0);
+    load_tile(n, d0, h0, w0);
+    store_tile();
+    __syncthreads();
+#pragma unroll 1
+    for (int tile = t_begin; tile < t_end; tile += t_step) {
+      const bool more = tile + t_step < t_end;
+      WX2_MARK(0);
+      if (more && !WX2_LOADS_IN) {
+        decode(tile + t_step, n, d0, h0, w0);
+        load_tile(n, d0, h0, w0);
+      }
+      WX2_MARK(1);
+      switch (wq) {
+        case 0: mfma_tile(std::integral_constant<int, 0>{}, more, tile + t_step); break;
+        case 1: mfma_tile(std::integral_constant<int, 1>{}, more, tile + t_step); break;
+        case 2: mfma_tile(std::integral_constant<int, 2>{}, more, tile + t_step); break;
+        default: mfma_tile(std::integral_constant<int, 3>{}, more, tile + t_step); break;
+      }
+      WX2_MARK(2);
+      __syncthreads();  // every wave is done reading this tile
+      WX2_MARK(3);
+      if (more) store_tile();
+      WX2_MARK(4);
+      __syncthreads();
+      WX2_MARK(5);
+#if WX2_STAMP
+      ++stamp_k;
+#endif
+    }
+  }
+
+  // group 1 -> LDS, group 0 adds and writes the slab: part[((blk*nCT + ct)*27 + tap)*1024 + co*32 + ci]
+  float* red = (float*)smem;  // [wq 4][j 7][co 32][ci 32]
+  const float inv = x2_pow2(-xexp) * x2_pow2(-yexp);
+  if (grp == 1) {
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        red[((wq * 7 + j) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[j][r];
+  }
+  __syncthreads();
+  if (grp == 0) {
+    float* slab = a.part + ((long)blockIdx.x * gridDim.y + ct) * 27 * 1024;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int tap = 7 * wq + j;
+      if (tap < 27) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
+          slab[tap * 1024 + co * 32 + l31] = (acc[j][r] + red[((wq * 7 + j) * 32 + co) * 32 + l31]) * inv;
+        }
+      }
+    }
+  }
+}
+
+int workers(long ntiles, int nCT) {
+  int ncu = 256;
+  int dev = 0, v = 0;
+  if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+      v > 0)
+    ncu = v;
+  long w = ncu / nCT;
+  if (w < 1) w = 1;
+  return (int)(ntiles < w ? ntiles : w);
+}
+
+}  // namespace
+
+// floats of scratch `part` dca_conv3d_wgrad_x3 needs
+extern "C" long dca_conv3d_wgrad_x2_workspace(int N, int Cx, int Cy, int D, int H, int W) {
+  if (N <= 0 || Cx <= 0 || Cy <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+  const long ntiles = (long)N * cdiv(D, TD) * cdiv(H, TH) * cdiv(W, TW);
+  const int nCT = cdiv(Cx, 32) * cdiv(Cy, 32);
+  return (long)workers(ntiles, nCT) * nCT * 27 * 1024;
+}
+
+// dw[cy*s_cy + cx*s_cx + tap] = sum dy[cy] * x[cx] shifted by the tap (3x3x3, stride 1, pad 1); x (N,Cx,D,H,W),
+// dy (N,Cy,D,H,W); x_amax / y_amax = device words with the bit patterns of max |x| / max |dy| (dca_amax_f32 or a producer).
+// Requires W % 4 == 0 and 16-byte aligned x / dy (callers fall back to dca_conv3d_wgrad otherwise).
+extern "C" int dca_conv3d_wgrad_x2(const float* x, const unsigned* x_amax, const float* dy, const unsigned* y_amax,
+                                   float* part, float* dw, int N, int Cx, int Cy, int D, int H, int W, long s_cy,
+                                   long s_cx, hipStream_t stream) {
+  DCA_REQUIRE(x && dy && part && dw && x_amax && y_amax && N > 0 && Cx > 0 && Cy > 0 && D > 0 && H > 0 && W > 0);
+  DCA_REQUIRE(W % 4 == 0 && ((((uintptr_t)x | (uintptr_t)dy) & 15) == 0));
+  DCA_REQUIRE((long)Cx * D * H * W * 4 < 0x7ffffff0L && (long)Cy * D * H * W * 4 < 0x7ffffff0L);
+  WX2Args a;
+  a.x = x; a.dy = dy; a.part = part; a.x_amax = x_amax; a.y_amax = y_amax; a.N = N; a.Cx = Cx; a.Cy = Cy; a.D = D; a.H = H; a.W = W;
+  a.nTD = cdiv(D, TD); a.nTH = cdiv(H, TH); a.nTW = cdiv(W, TW); a.nCxT = cdiv(Cx, 32);
+  const long ntiles = (long)N * a.nTD * a.nTH * a.nTW;
+  DCA_REQUIRE(ntiles < 0x7fffffffL);
+  const int nCT = a.nCxT * cdiv(Cy, 32);
+  DCA_REQUIRE(nCT <= 65535);
+  const int nblk = workers(ntiles, nCT);
+  hipError_t e = hipFuncSetAttribute((const void*)wgrad3_f16x2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     LDS_BYTES);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(wgrad3_f16x2_kernel, dim3(nblk, nCT), dim3(512), LDS_BYTES, stream, a);
+  int st = dca_launch_status();
+  if (st) return st;
+  return dca_internal_wgrad_reduce(part, dw, nblk, a.nCxT, nCT, 27, Cy, Cx, s_cy, s_cx, stream);
+}

@@ -129,12 +129,31 @@ __global__ __launch_bounds__(64) void bn_finalize_centered_kernel(const double* 
   stats[3 * C + c] = b - mean * g * invstd;
 }
 
+// The f16x2 convolution kernels (conv3d_f16x2.hip) scale their operands by a power of two taken from the tensor's max |.|;
+// the kernels that PRODUCE those operands (bn_apply: activations, bn_bwd_apply: gradients) emit it on the way: one
+// atomicMax per workgroup on the unsigned bit pattern of max |v| (monotonic for non-negative floats, order independent:
+// bitwise reproducible).  `amax` is a zero-initialised device word or null.
+__device__ __forceinline__ void amax_emit(float m, unsigned* amax) {
+  m = wave_max(m);
+  __shared__ float amax_red[16];
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) amax_red[w] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int i = 1; i < nw; ++i) m = fmaxf(m, amax_red[i]);
+    if (m > 0.f) atomicMax(amax, __float_as_uint(m));
+  }
+}
+
 // z = act(scale[c]*y + shift[c] + res_pre) + res_post
 __global__ void bn_apply_kernel(const float* __restrict__ y, const float* __restrict__ stats,
                                 const float* __restrict__ res_pre, const float* __restrict__ res_post,
-                                float* __restrict__ z, int C, long S, long total, float slope, int vec) {
+                                float* __restrict__ z, int C, long S, long total, float slope, int vec,
+                                unsigned* __restrict__ amax) {
   const float* scale = stats + 2 * C;
   const float* shift = stats + 3 * C;
+  float am = 0.f;
   if (vec) {
     const long total4 = total >> 2;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
@@ -146,6 +165,7 @@ __global__ void bn_apply_kernel(const float* __restrict__ y, const float* __rest
       v.x = act_apply(v.x, slope); v.y = act_apply(v.y, slope); v.z = act_apply(v.z, slope); v.w = act_apply(v.w, slope);
       if (res_post) { const float4 r = ((const float4*)res_post)[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
       ((float4*)z)[i] = v;
+      am = fmaxf(fmaxf(am, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
   } else {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -155,8 +175,10 @@ __global__ void bn_apply_kernel(const float* __restrict__ y, const float* __rest
       v = act_apply(v, slope);
       if (res_post) v += res_post[i];
       z[i] = v;
+      am = fmaxf(am, fabsf(v));
     }
   }
+  if (amax) amax_emit(am, amax);
 }
 
 // ------------------------------------------------------------------------------------ BN backward
@@ -231,7 +253,9 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* __res
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ y,
                                     const float* __restrict__ res_pre, const float* __restrict__ stats,
                                     const float* __restrict__ dgb, float* __restrict__ dy, float* __restrict__ g_out,
-                                    int C, long S, long total, float slope, int training, int vec) {
+                                    int C, long S, long total, float slope, int training, int vec,
+                                    unsigned* __restrict__ amax) {
+  float am = 0.f;
   if (vec) {
     const long total4 = total >> 2;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
@@ -251,7 +275,9 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* _
       }
       ((float4*)dy)[i] = make_float4(o[0], o[1], o[2], o[3]);
       if (g_out) ((float4*)g_out)[i] = make_float4(g[0], g[1], g[2], g[3]);
+      am = fmaxf(fmaxf(am, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
     }
+    if (amax) amax_emit(am, amax);
     return;
   }
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -265,7 +291,9 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* _
     if (training) v -= dgb[2 * C + c] + (yv - mean) * invstd * dgb[3 * C + c];
     dy[i] = v * sc;
     if (g_out) g_out[i] = g;
+    am = fmaxf(am, fabsf(v * sc));
   }
+  if (amax) amax_emit(am, amax);
 }
 
 // ------------------------------------------------------------------------------------ AvgPool3d(3, 2, 1)
@@ -697,19 +725,19 @@ extern "C" int dca_bn_finalize_centered(const double* part, int nchunk, const fl
 }
 
 extern "C" int dca_bn_apply(const float* y, const float* stats, const float* res_pre, const float* res_post, float* z,
-                            int N, int C, long S, float slope, hipStream_t stream) {
+                            int N, int C, long S, float slope, unsigned* amax, hipStream_t stream) {
   DCA_REQUIRE(y && stats && z && N > 0 && C > 0 && S > 0);
   const long total = (long)N * C * S;
   const uintptr_t al = (uintptr_t)y | (uintptr_t)z | (uintptr_t)res_pre | (uintptr_t)res_post;
   const int vec = (S % 4 == 0) && ((al & 15) == 0);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(vec ? total / 4 : total)), dim3(256), 0, stream, y, stats, res_pre,
-                     res_post, z, C, S, total, slope, vec);
+                     res_post, z, C, S, total, slope, vec, amax);
   return dca_launch_status();
 }
 
 extern "C" int dca_bn_backward(const float* dz, const float* y, const float* res_pre, const float* stats,
                                double* part, float* dgb, float* dy, float* g_out, int N, int C, long S, float slope,
-                               int training, hipStream_t stream) {
+                               int training, unsigned* amax, hipStream_t stream) {
   DCA_REQUIRE(dz && y && stats && part && dgb && dy && N > 0 && C > 0 && S > 0 && C <= 65535);
   int nchunk; long len;
   chunking(S, C, &nchunk, &len);
@@ -721,7 +749,7 @@ extern "C" int dca_bn_backward(const float* dz, const float* y, const float* res
                      (double)N * (double)S, dgb, C);
   const long total = (long)N * C * S;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(vec ? total / 4 : total)), dim3(256), 0, stream, dz, y, res_pre,
-                     stats, dgb, dy, g_out, C, S, total, slope, training, vec);
+                     stats, dgb, dy, g_out, C, S, total, slope, training, vec, amax);
   return dca_launch_status();
 }
 

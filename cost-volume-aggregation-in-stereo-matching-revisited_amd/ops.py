@@ -286,10 +286,55 @@ def _round_up(a, m):
 # ("bf16x3", conv3d_bf16x3.hip): fp32-grade accuracy (measured error vs fp64 slightly BELOW the fp32 MFMA kernel's)
 # at 1.3-1.75x the speed on every shape the networks use, 1/4 to 1/16 resolution (tools/x3_vs_fp32.py).
 # DCA_CONV=fp32 forces the fp32 MFMA kernel everywhere.
-CONV_X3 = os.environ.get("DCA_CONV", "x3") != "fp32"
+# DCA_CONV: "x2" (default) = 3x3x3 stride-1 convolutions and their weight gradients on the f16x2 split kernels
+# (conv3d_f16x2.hip: two f16 terms per operand, three products, power-of-two operand scaling from the tensor's max |.|);
+# "x3" = the bf16x3 split kernels for them; "fp32" = fp32 MFMA kernels everywhere.
+_CONV_MODE = os.environ.get("DCA_CONV", "x2")
+CONV_X3 = _CONV_MODE != "fp32"
+CONV_X2 = _CONV_MODE == "x2"
 DECONV_X3 = os.environ.get("DCA_DECONV", "x3") != "fp32"
 BN_FUSE = os.environ.get("DCA_BN_FUSE", "1") != "0"        # BatchNorm batch statistics from the conv epilogue (training)   # the transposed-convolution member of the family alone (A/B timing)
 _X3_MIN_WORKGROUPS = 1
+
+
+# ---- operand maxima for the f16x2 kernels -----------------------------------------------------------------------------
+# A "word" is a one-element int32 view holding the bit pattern of max |t| as an fp32 number.  Kernels that produce a
+# convolution operand emit it (BatchNorm apply / backward, the f16x2 convolution's own epilogue); it rides on the tensor
+# object as `_dca_amax = (word, t._version)` (an in-place change of t invalidates it).  Tensors without one get a read pass
+# (dca_amax_f32).  Words come from zero-filled pools and are used once; a pool allocated outside a stream capture is never
+# handed out inside one (a captured graph must zero its own words on every replay).
+AMAX_STATS = {"tagged": 0, "computed": 0}
+_AMAX_POOL_WORDS = 4096
+
+
+def _amax_word(device):
+    cap = torch.cuda.is_current_stream_capturing()
+    pool = getattr(_tls, "amax_pool", None)
+    if pool is None or pool[1] >= _AMAX_POOL_WORDS or pool[2] != cap or pool[0].device != device or \
+            pool[3] != torch.cuda.current_stream(device):
+        pool = _tls.amax_pool = [torch.zeros((_AMAX_POOL_WORDS,), device=device, dtype=torch.int32), 0, cap,
+                                 torch.cuda.current_stream(device)]
+    i = pool[1]
+    pool[1] = i + 1
+    return pool[0][i:i + 1]
+
+
+def _tag_amax(t, word):
+    t._dca_amax = (word, t._version)
+    return t
+
+
+def _amax_of(t):
+    """the max-|.| word of tensor t: the producer's if t carries a valid one, else one read pass over t"""
+    tag = getattr(t, "_dca_amax", None)
+    if tag is not None and tag[1] == t._version and tag[0].device == t.device:
+        AMAX_STATS["tagged"] += 1
+        return tag[0]
+    AMAX_STATS["computed"] += 1
+    word = torch.empty((1,), device=t.device, dtype=torch.int32)
+    _chk(_L().dca_amax_f32(_ptr(t), t.numel(), _ptr(word), _stream()), "dca_amax_f32")
+    _tag_amax(t, word)
+    return word
 
 
 def _x3_eligible(x, x2, ksize, stride, transposed, A, B):
@@ -356,19 +401,21 @@ def _out_dims(dims, ksize, stride, transposed):
 
 
 def _conv_sliced(x, x2, w_src, A, B, K, src_ab, flip, ksize, stride, transposed, scale=None, shift=None, slope=1.0,
-                 res_pre=None, res_post=None, want_stats=False):
+                 res_pre=None, res_post=None, want_stats=False, x_amax=None, emit_amax=False):
     """y = conv(x [, x2]) with A contraction channels and B output channels, as ceil(B / slice) launches that each
     write their channel slice of y (w_src is the PyTorch weight; src_ab / flip as in dca_conv3d_prep_weight).
     want_stats (no epilogue then): returns (y, part) where part holds the BatchNorm batch-statistics partials of y emitted
     by the convolution kernel itself (B * nchunk * 4 doubles, csrc/bn_fused_stats.h), or (y, None) when the kernel serving
     this shape has no such form."""
     y, part = _conv_sliced_impl(x, x2, w_src, A, B, K, src_ab, flip, ksize, stride, transposed, scale, shift, slope,
-                                res_pre, res_post, want_stats)
+                                res_pre, res_post, want_stats, x_amax, emit_amax)
     return (y, part) if want_stats else y
 
 
 def _conv_sliced_impl(x, x2, w_src, A, B, K, src_ab, flip, ksize, stride, transposed, scale, shift, slope, res_pre,
-                      res_post, want_stats):
+                      res_post, want_stats, x_amax=None, emit_amax=False):
+    """x_amax: the max-|.| word of x if the caller has it (f16x2 kernels; looked up / computed otherwise); emit_amax: tag y
+    with its own max-|.| word where the kernel serving this shape can emit one (inference chains conv -> conv)"""
     N = x.shape[0]
     Di, Hi, Wi = x.shape[2:]
     Do, Ho, Wo = _out_dims((Di, Hi, Wi), ksize, stride, transposed)
@@ -376,6 +423,28 @@ def _conv_sliced_impl(x, x2, w_src, A, B, K, src_ab, flip, ksize, stride, transp
     C1 = x.shape[1]
     width = _slice_width(ksize, stride, transposed, B)
     lib = _L()
+    if CONV_X2 and _x3_eligible(x, x2, ksize, stride, transposed, A, B):
+        def build_x2():
+            w2 = torch.empty((lib.dca_conv3d_x2_weight_bytes(A, B) // 2,), device=x.device, dtype=torch.int16)
+            _chk(lib.dca_conv3d_x2_prep_weight(_ptr(w_src), _ptr(w2), A, B, int(src_ab), int(flip), _stream()),
+                 "dca_conv3d_x2_prep_weight")
+            return w2
+        wx = _memo(("x2prep", A, B, int(src_ab), int(flip)), (w_src,), build_x2,
+                   (3, A, B, 0, 0, 27, int(src_ab), int(flip), B, 0))
+        xam = x_amax if x_amax is not None else _amax_of(x)
+        if want_stats:
+            nchunk = lib.dca_conv3d_x2_stats_chunks(N, B, Di, Hi, Wi)
+            part = torch.empty((B * nchunk * 4,), device=x.device, dtype=torch.float64)
+            _chk(lib.dca_conv3d_x2_forward_stats(_ptr(x), _ptr(xam), _ptr(wx), _ptr(y), _ptr(part), N, A, B, Di, Hi, Wi,
+                                                 _stream()), "dca_conv3d_x2_forward_stats")
+            return y, part
+        yam = _amax_word(x.device) if emit_amax else None
+        _chk(lib.dca_conv3d_x2_forward(_ptr(x), _ptr(xam), _ptr(wx), _ptr(y), _ptr(scale), _ptr(shift), _ptr(res_pre),
+                                       _ptr(res_post), float(slope), _ptr(yam), N, A, B, Di, Hi, Wi, _stream()),
+             "dca_conv3d_x2_forward")
+        if yam is not None:
+            _tag_amax(y, yam)
+        return y, None
     if _x3_eligible(x, x2, ksize, stride, transposed, A, B):
         def build_x3():
             w3 = torch.empty((lib.dca_conv3d_x3_weight_bytes(A, B) // 2,), device=x.device, dtype=torch.int16)
@@ -459,7 +528,7 @@ def conv3d_prepared(x, wt, A, Apad, B, ksize, stride, transposed):
 
 
 def _conv_forward_impl(x, x2, weight, stride, transposed, scale=None, shift=None, slope=1.0, res_pre=None,
-                       res_post=None, want_stats=False):
+                       res_post=None, want_stats=False, emit_amax=False):
     ksize = weight.shape[2]
     K = ksize ** 3
     if transposed:
@@ -470,16 +539,25 @@ def _conv_forward_impl(x, x2, weight, stride, transposed, scale=None, shift=None
         src_ab = 0
     assert x.shape[1] + (x2.shape[1] if x2 is not None else 0) == Cin, "conv3d: channel mismatch"
     return _conv_sliced(x, x2, weight, Cin, Cout, K, src_ab, 0, ksize, stride, transposed, scale, shift, slope,
-                        res_pre, res_post, want_stats)
+                        res_pre, res_post, want_stats, None, emit_amax)
 
 
-def _wgrad(x, dy, dw_view_ptr_tensor, dst_offset, Cx, Cy, ksize, stride, s_cy, s_cx):
+def _wgrad(x, dy, dw_view_ptr_tensor, dst_offset, Cx, Cy, ksize, stride, s_cy, s_cx, x_amax=None, y_amax=None):
     """dw[cy*s_cy + cx*s_cx + k] (+dst_offset floats) = sum dy[cy] * x[cx] (see dca_hip.h)."""
     N = x.shape[0]
     Di, Hi, Wi = x.shape[2:]
     Do, Ho, Wo = dy.shape[2:]
     dst = _vp(dw_view_ptr_tensor.data_ptr() + 4 * dst_offset)
     lib = _L()
+    if (CONV_X2 and CONV_X3 and ksize == 3 and stride == 1 and Wi % 4 == 0 and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0
+            and max(Cx, Cy) * Di * Hi * Wi * 4 < 0x7ffffff0):
+        xam = x_amax if x_amax is not None else _amax_of(x)
+        yam = y_amax if y_amax is not None else _amax_of(dy)
+        nws = lib.dca_conv3d_wgrad_x2_workspace(N, Cx, Cy, Di, Hi, Wi)
+        part = torch.empty((nws,), device=x.device, dtype=torch.float32)
+        _chk(lib.dca_conv3d_wgrad_x2(_ptr(x), _ptr(xam), _ptr(dy), _ptr(yam), _ptr(part), dst, N, Cx, Cy, Di, Hi, Wi,
+                                     s_cy, s_cx, _stream()), "dca_conv3d_wgrad_x2")
+        return
     if (CONV_X3 and ksize == 3 and stride == 1 and Wi % 4 == 0 and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0
             and max(Cx, Cy) * Di * Hi * Wi * 4 < 0x7ffffff0):
         nws = lib.dca_conv3d_wgrad_x3_workspace(N, Cx, Cy, Di, Hi, Wi)
@@ -541,7 +619,11 @@ class _Conv3d(torch.autograd.Function):
         x2 = _opt(x2, "conv3d.x2")
         ctx.save_for_backward(x, x2, weight)
         ctx.meta = (stride, transposed)
+        ctx.x_amax = None
         with torch.cuda.device_of(x):
+            if (CONV_X2 and x2 is None and not transposed and stride == 1 and weight.shape[2] == 3
+                    and _x3_eligible(x, None, 3, 1, False, weight.shape[1], weight.shape[0])):
+                ctx.x_amax = _amax_of(x)     # forward and weight gradient scale x by the same word
             if not want_stats:
                 return _conv_forward_impl(x, x2, weight, stride, transposed)
             y, part = _conv_forward_impl(x, x2, weight, stride, transposed, want_stats=True)
@@ -571,14 +653,14 @@ class _Conv3d(torch.autograd.Function):
                 Cout, Cin = weight.shape[0], weight.shape[1]
                 if need_x:
                     if stride == 1:
-                        gx = _conv_sliced(dy, None, weight, Cout, Cin, K, 1, 1, 3, 1, False)
+                        gx = _conv_sliced(dy, None, weight, Cout, Cin, K, 1, 1, 3, 1, False)   # dy's word: tag or one pass
                     else:
                         gx = _conv_sliced(dy, None, weight, Cout, Cin, K, 1, 0, 3, 2, True)
                         if gx.shape != x.shape:
                             raise RuntimeError("stride-2 conv backward needs even input dims")
                 if need_w:
                     gw = torch.empty_like(weight)
-                    _wgrad(x, dy, gw, 0, Cin, Cout, 3, stride, Cin * K, K)
+                    _wgrad(x, dy, gw, 0, Cin, Cout, 3, stride, Cin * K, K, x_amax=ctx.x_amax)
             else:
                 Cout, Cin = weight.shape[0], weight.shape[1]
                 w2 = weight.reshape(Cout, Cin)
@@ -611,7 +693,8 @@ def conv3d_fused_inference(x, weight, stride, transposed, scale, shift, slope, r
     x, weight = _req(x, "conv3d"), _req(weight, "conv3d.weight")
     with torch.cuda.device_of(x):
         return _conv_forward_impl(x, _opt(x2, "x2"), weight, int(stride), bool(transposed), _opt(scale, "scale"),
-                                  _opt(shift, "shift"), slope, _opt(res_pre, "res_pre"), _opt(res_post, "res_post"))
+                                  _opt(shift, "shift"), slope, _opt(res_pre, "res_pre"), _opt(res_post, "res_post"),
+                                  emit_amax=CONV_X2)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -662,7 +745,8 @@ class _BnAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, gamma, beta, running_mean, running_var, training, momentum, eps, slope, res_pre, res_post,
-                part=None):
+                part=None, amax=None):
+        """amax: zero word that receives max |z| (see _amax_word); the caller tags z with it"""
         y = _req(y, "batch_norm")
         res_pre, res_post = _opt(res_pre, "res_pre"), _opt(res_post, "res_post")
         N, C = y.shape[0], y.shape[1]
@@ -671,7 +755,7 @@ class _BnAct(torch.autograd.Function):
             stats = bn_stats_vector(y, gamma, beta, running_mean, running_var, training, momentum, eps, part)
             z = torch.empty_like(y)
             _chk(_L().dca_bn_apply(_ptr(y), _ptr(stats), _ptr(res_pre), _ptr(res_post), _ptr(z), N, C, S, float(slope),
-                                   _stream()), "dca_bn_apply")
+                                   _ptr(amax), _stream()), "dca_bn_apply")
         ctx.save_for_backward(y, stats, res_pre if slope != 1.0 else None)
         ctx.meta = (training, slope, res_pre is not None, res_post is not None)
         return z
@@ -691,13 +775,17 @@ class _BnAct(torch.autograd.Function):
             dy = torch.empty_like(y)
             want_g = has_pre and slope != 1.0 and ctx.needs_input_grad[9]
             g_out = torch.empty_like(y) if want_g else None
+            am = _amax_word(y.device) if CONV_X2 else None      # max |dy| for the convolution's backward kernels
             _chk(lib.dca_bn_backward(_ptr(dz), _ptr(y), _ptr(res_pre), _ptr(stats), _ptr(part), _ptr(dgb), _ptr(dy),
-                                     _ptr(g_out), N, C, S, float(slope), int(training), _stream()), "dca_bn_backward")
+                                     _ptr(g_out), N, C, S, float(slope), int(training), _ptr(am), _stream()),
+                 "dca_bn_backward")
+            if am is not None:
+                _tag_amax(dy, am)
         g_pre = None
         if has_pre and ctx.needs_input_grad[9]:
             g_pre = g_out if want_g else dz
         g_post = dz if (has_post and ctx.needs_input_grad[10]) else None
-        return dy, dgb[:C], dgb[C:2 * C], None, None, None, None, None, None, g_pre, g_post, None
+        return dy, dgb[:C], dgb[C:2 * C], None, None, None, None, None, None, g_pre, g_post, None, None
 
 
 _tls = threading.local()
@@ -763,7 +851,7 @@ class PrepackPlan:
         for out, desc, tensors in self.entries.values():
             kind, A, Bn, Apad, Bpad, K, src_ab, flip, Btotal, b_off = desc
             nch = (A + 15) // 16
-            total = out.numel()
+            total = out.numel() - (8 if kind == 3 else 0)    # kind 3: f16 elements in front of the 16-byte scale tail
             rows.append(struct.pack("<QQ12iq", tensors[0].data_ptr(), out.data_ptr(), kind, A, Bn, Apad, Bpad, K, src_ab,
                                     flip, Btotal, b_off, nch, 0, total))
         self.n = len(rows)
@@ -840,8 +928,11 @@ def bn_act(y, bn, slope=1.0, res_pre=None, res_post=None, stats_part=None):
     training = bn.training or bn.running_mean is None
     if _lp_dtype() is not None:
         raise RuntimeError("ops.reduced_precision is inference only: call the model in eval mode under torch.no_grad()")
+    am = _amax_word(y.device) if CONV_X2 else None          # max |z|: the next convolution's operand scale
     z = _BnAct.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, float(slope),
-                     res_pre, res_post, stats_part if training else None)
+                     res_pre, res_post, stats_part if training else None, am)
+    if am is not None:
+        _tag_amax(z, am)
     if bn.training and bn.num_batches_tracked is not None:
         pending = getattr(_tls, "pending", None)
         if pending is not None:

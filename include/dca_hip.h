@@ -23,7 +23,7 @@ extern "C" {
 
 /* Bumped whenever an argument list below changes; the ctypes loader (_lib.py) refuses a library built from another
  * version of this header. */
-#define DCA_ABI_VERSION 9
+#define DCA_ABI_VERSION 10
 int dca_abi_version(void);
 
 /* storage types of the reduced-precision inference path (0 = fp32) */
@@ -126,7 +126,8 @@ int dca_conv1_x3_forward(const float* x, const float* x2, const void* wfrag, flo
  * (kind 1) work (prep_many.hip) -- a training step re-packs every conv weight after the optimizer update, and ~130
  * separate 5-us launches cost more than the work.  table: n device-resident 72-byte records
  *   { const float* src; void* dst; int kind, A, Bn, Apad, Bpad, K, src_ab, flip, Btotal, b_off, NCH, pad; long total; }
- * (kind 1 uses A, Bn, src_ab, flip, NCH = ceil(A/16), total = dca_conv3d_x3_weight_bytes/2; kind 0 total = K*Apad*Bpad). */
+ * (kind 1 uses A, Bn, src_ab, flip, NCH = ceil(A/16), total = dca_conv3d_x3_weight_bytes/2; kind 0 total = K*Apad*Bpad;
+ * kind 3 = dca_conv3d_x2_prep_weight with the fields of kind 1 and total = (dca_conv3d_x2_weight_bytes - 16)/2). */
 int dca_conv3d_prep_many(const void* table, int n, hipStream_t stream);
 
 /* "bf16x3" split-precision 3x3x3 / stride-1 / pad-1 convolution (conv3d_bf16x3.hip): every fp32 operand is split exactly
@@ -186,6 +187,33 @@ long dca_conv3d_wgrad_x3_workspace(int N, int Cx, int Cy, int D, int H, int W);
 int dca_conv3d_wgrad_x3(const float* x, const float* dy, float* part, float* dw, int N, int Cx, int Cy, int D, int H,
                         int W, long s_cy, long s_cx, hipStream_t stream);
 
+/* "f16x2" split-precision 3x3x3 / stride-1 / pad-1 convolution and weight gradient (conv3d_f16x2.hip,
+ * conv3d_wgrad_f16x2.hip) -- the kernels the models run: each fp32 operand is scaled by a power of two taken from its
+ * tensor's max |.| (scaled maximum in [2^14, 2^15): inside the f16 range whatever the tensor's magnitude), split into two
+ * f16 terms (|x - h - l| <= 2^-22 |x|) and the three partial products >= 2^-11 run on the f16 matrix pipe with fp32
+ * accumulation; the result is scaled back in the epilogue.  Half the matrix-pipe cycles of the bf16x3 kernels at the
+ * same measured error against fp64.  Same operators as dca_conv3d_x3_forward / dca_conv3d_wgrad_x3
+ * (models/submodule.py:121-124, models/augment/cva.py:13-55) and, with src_ab = 1 / flip = 1, their backward-data.
+ *   dca_amax_f32: word <- bit pattern of max |x[0..n)| as an fp32 number (a memset and one read pass); the BatchNorm
+ *       kernels emit the same word for the tensors they write (dca_bn_apply / dca_bn_backward, `amax`).
+ *   dca_conv3d_x2_weight_bytes / dca_conv3d_x2_prep_weight: packed image (fragments, then {2^ew, 2^-ew, max |w|, 0});
+ *       argument meaning of dca_conv3d_x3_prep_weight.
+ *   dca_conv3d_x2_forward[_stats]: contracts of dca_conv3d_x3_forward[_stats]; x_amax = the operand's word; y_amax (may be
+ *       null) = zero-initialised word that receives max |y| for the next convolution.
+ *   dca_conv3d_wgrad_x2: contract of dca_conv3d_wgrad_x3; x_amax / y_amax = the words of x and dy. */
+int dca_amax_f32(const float* x, long n, unsigned* word, hipStream_t stream);
+long dca_conv3d_x2_weight_bytes(int Cin, int Cout);
+int dca_conv3d_x2_prep_weight(const float* w, void* wx, int A, int B, int src_ab, int flip, hipStream_t stream);
+int dca_conv3d_x2_forward(const float* x, const unsigned* x_amax, const void* wx, float* y, const float* scale,
+                          const float* shift, const float* res_pre, const float* res_post, float slope, unsigned* y_amax,
+                          int N, int Cin, int Cout, int D, int H, int W, hipStream_t stream);
+long dca_conv3d_x2_stats_chunks(int N, int Cout, int D, int H, int W);
+int dca_conv3d_x2_forward_stats(const float* x, const unsigned* x_amax, const void* wx, float* y, double* stat_part,
+                                int N, int Cin, int Cout, int D, int H, int W, hipStream_t stream);
+long dca_conv3d_wgrad_x2_workspace(int N, int Cx, int Cy, int D, int H, int W);
+int dca_conv3d_wgrad_x2(const float* x, const unsigned* x_amax, const float* dy, const unsigned* y_amax, float* part,
+                        float* dw, int N, int Cx, int Cy, int D, int H, int W, long s_cy, long s_cx, hipStream_t stream);
+
 /* Single-output-channel 3x3x3 convolution (the logit heads: nn.Conv3d(32, 1, 3, padding=1, bias=False),
  * models/gwcnet_dca_g.py:154-168 `classif*.2`, models/augment/cva.py:51-53 `classify.2`).  w is the PyTorch weight
  * (1,C,3,3,3) as is.  The 27 taps become a GEMM axis so forward / weight gradient reuse the matrix-core kernels:
@@ -206,17 +234,20 @@ int dca_conv3d_c1_bwd_data(const float* dy, const float* w, float* dx, int N, in
  *                  statistics and updates running_mean/var (unbiased), else uses the running stats.
  * dca_bn_apply:    z = act(scale*y + shift + res_pre) + res_post.
  * dca_bn_backward: given dz -> dy (grad of the conv output), dgb = [dgamma | dbeta | ...] (4*C floats),
- *                  optional g_out = grad w.r.t. res_pre (= dz masked by the activation). */
+ *                  optional g_out = grad w.r.t. res_pre (= dz masked by the activation).
+ * amax (dca_bn_apply: of z, dca_bn_backward: of dy; may be null): a ZERO-initialised device word that receives the bit
+ *                  pattern of max |.| of the tensor written, as an fp32 number -- the operand maximum the f16x2
+ *                  convolution kernels below scale by (order-independent atomicMax on unsigned patterns). */
 int dca_bn_num_chunks(int C, long S);
 int dca_bn_stats(const float* x, double* part, int N, int C, long S, hipStream_t stream);
 int dca_bn_finalize(const double* part, int nchunk, double count, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float momentum, float eps, int training, float* stats,
                     int C, hipStream_t stream);
 int dca_bn_apply(const float* y, const float* stats, const float* res_pre, const float* res_post, float* z, int N,
-                 int C, long S, float slope, hipStream_t stream);
+                 int C, long S, float slope, unsigned* amax, hipStream_t stream);
 int dca_bn_backward(const float* dz, const float* y, const float* res_pre, const float* stats, double* part,
                     float* dgb, float* dy, float* g_out, int N, int C, long S, float slope, int training,
-                    hipStream_t stream);
+                    unsigned* amax, hipStream_t stream);
 
 /* ---- AvgPool3d((3,3,3), stride 2, padding 1) -- models/augment/cva.py:39 ---------------------------- */
 int dca_avgpool3d_fwd(const float* x, float* y, long NC, int Di, int Hi, int Wi, hipStream_t stream);

@@ -118,6 +118,17 @@ def test_softargmin(mode):
 
 
 # ------------------------------------------------------------------------------------- convolutions
+SPLIT_FAMILIES = ["bf16x3", "f16x2"]
+
+
+def _family(monkeypatch, ops, fam):
+    """conv kernel family: fp32mfma = fp32 MFMA kernels everywhere; bf16x3 = the three-term bf16 split kernels;
+    f16x2 (shipped default) = the two-term f16 split kernels for the 3x3x3 stride-1 convolution and its weight gradient,
+    bf16x3 for the transposed / 1x1x1 members"""
+    monkeypatch.setattr(ops, "CONV_X3", fam != "fp32mfma")
+    monkeypatch.setattr(ops, "CONV_X2", fam == "f16x2")
+
+
 CONV_CASES = [
     # cin, cout, k, stride, transposed, dims, N
     (40, 32, 3, 1, False, (4, 6, 10), 2),
@@ -141,17 +152,20 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("x3", [False, True], ids=["fp32mfma", "bf16x3"])
+@pytest.mark.parametrize("fam", ["fp32mfma", "bf16x3", "f16x2"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[str(c[:5]) + str(c[5]) for c in CONV_CASES])
-def test_conv3d(case, x3, monkeypatch):
+def test_conv3d(case, fam, monkeypatch):
     """x3 = False: the fp32 MFMA kernels everywhere; True: 3x3x3 stride-1 forward / backward-data and the transposed
     convolution (= backward-data of the stride-2 one) on the bf16x3 split kernels (the shipped default), everything else
     unchanged"""
     _, ops = _mods()
-    monkeypatch.setattr(ops, "CONV_X3", x3)
+    _family(monkeypatch, ops, fam)
+    x3 = fam != "fp32mfma"
     if x3 and not (case[2] == 3 and case[1] > 1):
         pytest.skip("bf16x3 kernels: 3x3x3 stride-1 convolutions, transposed convolutions (<= 32 output channels) and the "
                     "backward-data of the stride-2 ones; the 1x1x1 kernel has its own test")
+    if fam == "f16x2" and (case[3] != 1 or case[4]):
+        pytest.skip("f16x2 kernels: 3x3x3 stride-1 convolutions only")
     cin, cout, k, stride, transposed, dims, N = case
     x = seeded_tensor(f"cv.x{case}", (N, cin) + dims)
     wshape = (cin, cout, k, k, k) if transposed else (cout, cin, k, k, k)
@@ -183,12 +197,13 @@ X3_CASES = [
 ]
 
 
+@pytest.mark.parametrize("fam", SPLIT_FAMILIES)
 @pytest.mark.parametrize("case", X3_CASES, ids=[str(c) for c in X3_CASES])
-def test_conv3d_bf16x3_path(case, monkeypatch):
-    """the bf16x3 split kernel (conv3d_bf16x3.hip) that serves the large 3x3x3 stride-1 convolutions: forward and,
-    through autograd, backward-data, at the same tolerance as the fp32 MFMA kernel"""
+def test_conv3d_bf16x3_path(case, fam, monkeypatch):
+    """the split kernels (conv3d_f16x2.hip -- shipped -- and conv3d_bf16x3.hip) that serve the large 3x3x3 stride-1
+    convolutions: forward and, through autograd, backward-data, at the same tolerance as the fp32 MFMA kernel"""
     _, ops = _mods()
-    monkeypatch.setattr(ops, "CONV_X3", True)
+    _family(monkeypatch, ops, fam)
     monkeypatch.setattr(ops, "_X3_MIN_WORKGROUPS", 1)
     cin, cout, dims, N = case
     x = seeded_tensor(f"x3.x{case}", (N, cin) + dims)
@@ -373,12 +388,13 @@ def test_convbn3d_training_uses_fused_statistics(monkeypatch):
     assert res[True][6] == res[False][6] == 1
 
 
-def test_conv3d_bf16x3_random_shapes(monkeypatch):
+@pytest.mark.parametrize("fam", SPLIT_FAMILIES)
+def test_conv3d_bf16x3_random_shapes(fam, monkeypatch):
     """randomised shapes (tiny dims, channel counts off the 16/32 grid, W on and off the aligned path, batches) through
-    the bf16x3 forward / backward-data / weight-gradient kernels against fp64 (tools/x3_stress.py runs 60 of these)"""
+    the split forward / backward-data / weight-gradient kernels against fp64 (tools/x3_stress.py runs 60 of these)"""
     import random
     _, ops = _mods()
-    monkeypatch.setattr(ops, "CONV_X3", True)
+    _family(monkeypatch, ops, fam)
     rnd = random.Random(3)
     g = torch.Generator().manual_seed(3)
     for _ in range(16):
@@ -397,9 +413,11 @@ def test_conv3d_bf16x3_random_shapes(monkeypatch):
             assert err <= 1e-5 * (ref.abs().max().item() + 1e-30), (name, (N, cin, cout, D, H, W), err)
 
 
-def test_conv3d_bf16x3_is_fp32_grade(monkeypatch):
-    """against an fp64 convolution the split kernel must be as accurate as the fp32 MFMA kernel (it drops only
-    partial products below 2^-23 relative), including for operands spanning many binades"""
+@pytest.mark.parametrize("fam", SPLIT_FAMILIES)
+def test_conv3d_bf16x3_is_fp32_grade(fam, monkeypatch):
+    """against an fp64 convolution the split kernels must be as accurate as the fp32 MFMA kernel (bf16x3 drops only
+    partial products below 2^-23 relative; f16x2 represents an operand to 2^-22 of its magnitude or 2^-40 of the tensor's
+    maximum), including for operands spanning many binades"""
     _, ops = _mods()
     monkeypatch.setattr(ops, "_X3_MIN_WORKGROUPS", 1)
     g = torch.Generator().manual_seed(7)
@@ -407,9 +425,9 @@ def test_conv3d_bf16x3_is_fp32_grade(monkeypatch):
     w = torch.randn(32, 32, 3, 3, 3, generator=g) * torch.exp2(torch.randint(-6, 6, (32, 32, 3, 3, 3), generator=g).float())
     ref = F.conv3d(x.double(), w.double(), None, 1, 1)
     xg, wg = x.to(DEV), w.to(DEV)
-    monkeypatch.setattr(ops, "CONV_X3", True)
+    _family(monkeypatch, ops, fam)
     e_x3 = (ops.conv3d(xg, wg, 1, False).cpu().double() - ref).abs().max().item()
-    monkeypatch.setattr(ops, "CONV_X3", False)
+    _family(monkeypatch, ops, "fp32mfma")
     e_f32 = (ops.conv3d(xg, wg, 1, False).cpu().double() - ref).abs().max().item()
     e_cpu = (F.conv3d(x, w, None, 1, 1).double() - ref).abs().max().item()
     scale = ref.abs().max().item()
@@ -418,9 +436,10 @@ def test_conv3d_bf16x3_is_fp32_grade(monkeypatch):
 
 @pytest.mark.parametrize("case", [(1, 32, 32, (2, 4, 16)), (2, 40, 32, (5, 7, 20)), (1, 64, 33, (3, 9, 36)), (1, 16, 27, (6, 6, 12))],
                          ids=str)
-def test_wgrad_bf16x3(case, monkeypatch):
-    """weight gradient on the bf16x3 split kernel (conv3d_wgrad_bf16x3.hip) against an fp64 reference: at least as
-    accurate as the fp32 MFMA kernel, and bitwise reproducible"""
+@pytest.mark.parametrize("fam", SPLIT_FAMILIES)
+def test_wgrad_bf16x3(case, fam, monkeypatch):
+    """weight gradient on the split kernels (conv3d_wgrad_f16x2.hip / conv3d_wgrad_bf16x3.hip) against an fp64 reference:
+    at least as accurate as the fp32 MFMA kernel, and bitwise reproducible"""
     _, ops = _mods()
     N, cx, cy, dims = case
     x, dy = seeded_tensor(f"wx3.x{case}", (N, cx) + dims), seeded_tensor(f"wx3.g{case}", (N, cy) + dims)
@@ -428,7 +447,7 @@ def test_wgrad_bf16x3(case, monkeypatch):
     xg, dyg = x.to(DEV), dy.to(DEV)
 
     def run(x3):
-        monkeypatch.setattr(ops, "CONV_X3", x3)
+        _family(monkeypatch, ops, fam if x3 else "fp32mfma")
         gw = torch.empty(cy, cx, 3, 3, 3, device=DEV)
         ops._wgrad(xg, dyg, gw, 0, cx, cy, 3, 1, cx * 27, 27)
         return gw
@@ -439,19 +458,23 @@ def test_wgrad_bf16x3(case, monkeypatch):
     assert torch.equal(g3, run(True))
 
 
-def test_conv3d_bf16x3_fused_epilogue(monkeypatch):
-    """y = act(conv * scale + shift + res_pre) + res_post through the C ABI of the split kernel"""
+@pytest.mark.parametrize("fam", SPLIT_FAMILIES)
+def test_conv3d_bf16x3_fused_epilogue(fam, monkeypatch):
+    """y = act(conv * scale + shift + res_pre) + res_post through the C ABI of the split kernels"""
     _, ops = _mods()
     N, cin, cout, dims = 2, 32, 40, (5, 9, 20)
     x = seeded_tensor("x3e.x", (N, cin) + dims); w = seeded_tensor("x3e.w", (cout, cin, 3, 3, 3)) * 0.05
     sc = seeded_tensor("x3e.s", (cout,)).abs() + 0.5; sh = seeded_tensor("x3e.b", (cout,))
     rp = seeded_tensor("x3e.p", (N, cout) + dims); rq = seeded_tensor("x3e.q", (N, cout) + dims)
     ref = F.leaky_relu(F.conv3d(x, w, None, 1, 1) * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1) + rp, 0.1) + rq
-    monkeypatch.setattr(ops, "CONV_X3", True)
+    _family(monkeypatch, ops, fam)
     monkeypatch.setattr(ops, "_X3_MIN_WORKGROUPS", 1)
     y = ops._conv_sliced(x.to(DEV), None, w.to(DEV), cin, cout, 27, 0, 0, 3, 1, False, sc.to(DEV), sh.to(DEV), 0.1,
-                         rp.to(DEV), rq.to(DEV))
+                         rp.to(DEV), rq.to(DEV), emit_amax=True)
     close(y, ref, 1e-5, "fused")
+    if fam == "f16x2":   # the epilogue's own max |y| word, for the next convolution
+        word = y._dca_amax[0].view(torch.float32).item()
+        assert word == y.abs().max().item(), (word, y.abs().max().item())
 
 
 def test_frozen_weights_cache_is_exact_and_scoped():
