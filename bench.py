@@ -137,6 +137,16 @@ def kernel_roofline(device, dtype="f32"):
             ops._chk(lib.dca_conv3d_x3_forward(ops._ptr(x), ops._ptr(wx), ops._ptr(y), None, None, None, None, 1.0, 1,
                                                32, 32, d, h, w, ops._stream()), "x3 forward")
 
+        def run_x2_factory():
+            w2 = torch.empty((lib.dca_conv3d_x2_weight_bytes(32, 32) // 2,), device=device, dtype=torch.int16)
+            ops._chk(lib.dca_conv3d_x2_prep_weight(ops._ptr(wgt), ops._ptr(w2), 32, 32, 0, 0, ops._stream()), "x2 prep")
+            xam = ops._amax_of(x)     # in the network the producer of x (BatchNorm apply) emits this word
+
+            def run_x2():
+                ops._chk(lib.dca_conv3d_x2_forward(ops._ptr(x), ops._ptr(xam), ops._ptr(w2), ops._ptr(y), None, None, None,
+                                                   None, 1.0, None, 1, 32, 32, d, h, w, ops._stream()), "x2 forward")
+            return run_x2
+
         cases = []
         if dtype != "f32":
             # reduced-precision run: its dominant kernel is conv3_lp_kernel on 2-byte tensors.  86.6 GFLOP over 200.6 MB
@@ -148,26 +158,33 @@ def kernel_roofline(device, dtype="f32"):
             cases.append((f"conv3_lp_kernel<{dtype}> (3x3x3 32->32 @1/4 res, {dtype} storage in and out, one MFMA product per "
                           "multiply, fp32 accumulation, fused affine + ReLU epilogue)", "conv3_lp", PEAK_BF16_MFMA_TFLOPS,
                           lambda: ops.conv3d_lp(xl, wgt, lp, sc_, sh_, 0.0)))
+        if ops.CONV_X3 and ops.CONV_X2:
+            cases.append(("conv3_f16x2_kernel (3x3x3 32->32 @1/4 res; fp32-grade via power-of-two operand scaling + 2-way f16 "
+                          "split, 3 f16 MFMA products per fp32 product)", "conv3_f16x2", PEAK_BF16_MFMA_TFLOPS / 3.0,
+                          run_x2_factory()))
         if ops.CONV_X3:
             cases.append(("conv3_bf16x3_kernel (3x3x3 32->32 @1/4 res; fp32 via exact 3-way bf16 split, 6 bf16 MFMA "
                           "products per fp32 product)", "conv3_bf16x3", PEAK_BF16_MFMA_TFLOPS / 6.0, run_x3))
         cases.append(("conv3_mfma_kernel<S1,Cout32,CK8,tile 4x8x16> (3x3x3 32->32 @1/4 res, fp32 MFMA)", "conv3_mfma",
                       PEAK_FP32_MFMA_TFLOPS, lambda: ops.conv3d_prepared(x, wt, 32, cpad, 32, 3, 1, False)))
-        def run_wgrad(x3):
+        def run_wgrad(x3, x2=False):
             def f():
-                keep = ops.CONV_X3
-                ops.CONV_X3 = x3
+                keep = ops.CONV_X3, ops.CONV_X2
+                ops.CONV_X3, ops.CONV_X2 = x3, x2
                 try:
                     ops._wgrad(x, x, wgt.new_empty(wgt.shape), 0, 32, 32, 3, 1, 32 * 27, 27)
                 finally:
-                    ops.CONV_X3 = keep
+                    ops.CONV_X3, ops.CONV_X2 = keep
             return f
 
+        if ops.CONV_X3 and ops.CONV_X2:
+            cases.append(("wgrad3_f16x2_kernel (+reduce) (dW of 3x3x3 32->32 @1/4 res; same 3-product f16 split)",
+                          "wgrad3_f16x2", PEAK_BF16_MFMA_TFLOPS / 3.0, run_wgrad(True, True)))
         if ops.CONV_X3:
             cases.append(("wgrad3_bf16x3_kernel (+reduce) (dW of 3x3x3 32->32 @1/4 res; same 6-product bf16 split)",
-                          "wgrad3_bf16x3", PEAK_BF16_MFMA_TFLOPS / 6.0, run_wgrad(True)))
+                          "wgrad3_bf16x3", PEAK_BF16_MFMA_TFLOPS / 6.0, run_wgrad(True, False)))
         cases.append(("wgrad3_kernel<S1> (+reduce) (dW of 3x3x3 32->32 @1/4 res, fp32 MFMA)", "wgrad3",
-                      PEAK_FP32_MFMA_TFLOPS, run_wgrad(False)))
+                      PEAK_FP32_MFMA_TFLOPS, run_wgrad(False, False)))
         # the transposed convolution of the cva blocks (64 -> 32, 1/8 -> 1/4 res), same 6-product split: its own FLOP count
         if ops.CONV_X3 and ops.DECONV_X3:
             xc = torch.randn(1, 64, d // 2, h // 2, w // 2, device=device)
@@ -217,6 +234,11 @@ def kernel_roofline(device, dtype="f32"):
                 out[name]["algorithmic_bytes"] = lp_bytes
                 out[name]["hbm_view"] = {"achieved": round(lp_bytes / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
                                          "unit": "GB/s", "frac": round(lp_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+            if key in ("conv3_f16x2", "wgrad3_f16x2"):
+                out[name]["peak_note"] = "dense f16 MFMA peak (2500) / 3 products per fp32 product"
+                out[name]["executed_f16"] = {"achieved": round(3 * tf, 1), "peak": PEAK_BF16_MFMA_TFLOPS,
+                                             "unit": "TFLOP/s", "frac": round(3 * tf / PEAK_BF16_MFMA_TFLOPS, 4)}
+                out[name]["vs_fp32_mfma_peak"] = round(tf / PEAK_FP32_MFMA_TFLOPS, 4)
             if key in ("conv3_bf16x3", "wgrad3_bf16x3", "deconv3_bf16x3"):
                 out[name]["peak_note"] = "dense bf16 MFMA peak (2500) / 6 products per fp32 product"
                 out[name]["executed_bf16"] = {"achieved": round(6 * tf, 1), "peak": PEAK_BF16_MFMA_TFLOPS,
@@ -415,6 +437,8 @@ def main():
             torch.cuda.synchronize()
 
     fence()
+    from dcanet_amd import ops as _ops_c
+    amax0 = dict(_ops_c.AMAX_STATS)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -439,10 +463,14 @@ def main():
                          "at a shape with negligible GPU work: `bench.py --shape 64x128x32 --batch 1` = 10.2 ms per "
                          "training step (~900 launches), 2.2 ms per eval forward (DESIGN.md section 5)",
             "higher_is_better": True,
+            # f16x2 kernels: per step, operand maxima that came with the tensor (emitted by its producer) / needed a read pass
+            "f16x2_operand_maxima_per_step": {k: (_ops_c.AMAX_STATS[k] - amax0[k]) / args.steps for k in amax0},
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "dtype_note": ("fp32 tensors and fp32 accumulation everywhere; the 3x3x3 stride-1 convolutions and their weight "
-                           "gradients evaluate each fp32 product exactly-split into three bf16 terms (six bf16 MFMA products, "
-                           "dropped terms <= 2^-23): measured against fp64 as accurate as the fp32 MFMA kernels "
+                           "gradients scale each fp32 operand by a power of two taken from its tensor's max |.| and split it "
+                           "into two f16 terms (three f16 MFMA products, operand error <= 2^-22; DCA_CONV=x3: three bf16 "
+                           "terms, six products), the transposed and 1x1x1 convolutions use the three-term bf16 split: "
+                           "measured against fp64 as accurate as the fp32 MFMA kernels "
                            "(tests/test_gpu_parity.py::test_conv3d_bf16x3_is_fp32_grade); DCA_CONV=fp32 selects the fp32 MFMA "
                            "kernels") if args.dtype == "f32" and _conv_x3() else
                           ("fp32 MFMA kernels everywhere (DCA_CONV=fp32)" if args.dtype == "f32" else
