@@ -67,7 +67,7 @@ constexpr int NB_ITEMS = 2 * NVOX;                 // (k half, voxel) staging it
 constexpr int KB = (NB_ITEMS + 511) / 512;         // 5
 constexpr int NROWS = 2 * ID * IH;                 // 120 (k half, d, h) halo rows: 4 aligned quads + 2 edge voxels each
 constexpr int NQUAD = NROWS * 4, NEDGE = NROWS * 2;  // aligned path: 480 quad items (8 x b128), 240 edge items (8 x b32)
-static_assert(NQUAD <= 512 && NEDGE <= 512, "one quad / edge item per thread");
+static_assert(NQUAD <= 512 && NEDGE % 8 == 0 && NEDGE / 8 <= 64, "one quad / edge item per thread");
 constexpr int NA_ITEMS = A_SLAB / 16;              // 1152 b128 per slab
 constexpr int KA = (NA_ITEMS + 511) / 512;         // 3
 
@@ -84,9 +84,9 @@ struct X2Args {
   int D, H, W;
   int nTD, nTH, nTW;
   double* stat_part;         // STATS: one partial {K, n, s, q} per (channel, workgroup): bn_fused_stats.h
-  const unsigned* x_amax;    // bit pattern of max |x| (fp32), device word
+  const unsigned* x_amax;    // max |x|: DCA_AMAX_SLOTS device words (dca_common.h)
   const float* wtail;        // {2^ew, 2^-ew} behind the packed weight image
-  unsigned* y_amax;          // optional: receives the bit pattern of max |y| (zero-initialised device word)
+  unsigned* y_amax;          // optional: receives max |y| (DCA_AMAX_SLOTS zero-initialised device words)
 };
 
 constexpr int STAT_LDS = 8 * FS_WAVE_FLOATS * 4;
@@ -98,15 +98,6 @@ __device__ __forceinline__ void split2(float v, float s, _Float16& h, _Float16& 
   l = (_Float16)(u - (float)h);   // the residual is exact in fp32
 }
 
-// power of two that brings a tensor whose max |.| has the bit pattern `bits` into [2^14, 2^15); 1 for an all-zero tensor.
-// The exponent is clamped to [-100, 60]: beyond that the data are fp32 denormals / infinities and nothing is to be kept.
-__device__ __forceinline__ int x2_scale_exp(unsigned bits) {
-  const int e = (int)((bits >> 23) & 255);
-  int ex = e == 0 ? 0 : 141 - e;
-  ex = ex > 60 ? 60 : (ex < -100 ? -100 : ex);
-  return ex;
-}
-__device__ __forceinline__ float x2_pow2(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
 
 // STATS: the raw convolution output feeds a training-mode BatchNorm -- the kernel also produces, per channel and workgroup,
 // the partial statistics {K, n, sum (y - K), sum (y - K)^2} that dca_bn_finalize_centered consumes (bn_fused_stats.h), so the
@@ -160,7 +151,7 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
   const int P = a.NCH * 3;   // phases: (chunk, kd)
   const long wbytes = (long)P * A_SLAB;
   const __amdgpu_buffer_rsrc_t wr = dca_rsrc((const char*)a.wx + (long)cblk * wbytes, wbytes);
-  const int xexp = x2_scale_exp(__builtin_amdgcn_readfirstlane(*a.x_amax));
+  const int xexp = x2_scale_exp(dca_amax_get(a.x_amax));
   const float xs = x2_pow2(xexp);                        // operand scale
   const float inv = x2_pow2(-xexp) * a.wtail[1];         // accumulator -> fp32 result
 
@@ -200,9 +191,11 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
       const int row = tid >> 2, q = tid & 3, kh = row / (ID * IH), rem = row - kh * (ID * IH), id = rem / IH, ih = rem - id * IH;
       item_crd[0] = (tid < NQUAD) ? (id | (ih << 8) | ((1 + 4 * q) << 16) | (kh << 24)) : -1;
     }
-    {
-      const int row = tid >> 1, side = tid & 1, kh = row / (ID * IH), rem = row - kh * (ID * IH), id = rem / IH, ih = rem - id * IH;
-      item_crd[1] = (tid < NEDGE) ? (id | (ih << 8) | ((side ? IW - 1 : 0) << 16) | (kh << 24)) : -1;
+    {  // the 240 edge items dealt evenly over the eight waves (30 lanes each): their scattered 4-byte loads cost the
+       // memory pipe one cache line per lane, so no wave should carry more of them than the others
+      const int e = wv * (NEDGE / 8) + lane;
+      const int row = e >> 1, side = e & 1, kh = row / (ID * IH), rem = row - kh * (ID * IH), id = rem / IH, ih = rem - id * IH;
+      item_crd[1] = (lane < NEDGE / 8) ? (id | (ih << 8) | ((side ? IW - 1 : 0) << 16) | (kh << 24)) : -1;
     }
   } else {
 #pragma unroll
@@ -220,19 +213,26 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
           (int)((unsigned)wi < (unsigned)a.W);
     return (c0 * cstride + (di * a.H + hi) * a.W + wi) * 4;
   };
-  auto load_B = [&](int n, int d0, int h0, int w0, int chunk) __attribute__((always_inline)) {
+  // VEC: part 0 = channels 0-3 of the thread's quad and of its edge voxel, part 1 = channels 4-7 (a channel's quads and
+  // edge voxels are requested back to back: an edge voxel lies in the 128-byte line of its row's own quads or of the
+  // neighbouring tile's, so half of the edge requests hit lines the quads have just brought into the L1); otherwise
+  // part 0 = items 0-2, part 1 = items 3-4; part -1: everything
+  auto load_B = [&](int part, int n, int d0, int h0, int w0, int chunk) __attribute__((always_inline)) {
     const __amdgpu_buffer_rsrc_t xr = dca_rsrc(a.x + (long)n * sample, sample * 4);
     if constexpr (VEC) {
-      int c0, okv;
-      const int offq = item_off(item_crd[0], d0, h0, w0, chunk, c0, okv);  // a quad is inside W or outside as a whole
+      int c0, okq, c0e, oke;
+      const int offq = item_off(item_crd[0], d0, h0, w0, chunk, c0, okq);  // a quad is inside W or outside as a whole
+      const int offe = item_off(item_crd[1], d0, h0, w0, chunk, c0e, oke);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) rq[j] = dca_bload4(xr, offq + j * cstride * 4, okv & (int)(c0 + j < a.Cin));
-      const int offe = item_off(item_crd[1], d0, h0, w0, chunk, c0, okv);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) re[j] = dca_bload1(xr, offe + j * cstride * 4, okv & (int)(c0 + j < a.Cin));
+      for (int j = 0; j < 8; ++j) {
+        if ((part == 0 && j >= 4) || (part == 1 && j < 4)) continue;
+        rq[j] = dca_bload4(xr, offq + j * cstride * 4, okq & (int)(c0 + j < a.Cin));
+        re[j] = dca_bload1(xr, offe + j * cstride * 4, oke & (int)(c0e + j < a.Cin));
+      }
     } else {
 #pragma unroll
       for (int k = 0; k < KB; ++k) {
+        if ((part == 0 && k >= 3) || (part == 1 && k < 3)) continue;
         int c0, okv;
         const int off = item_off(item_crd[k], d0, h0, w0, chunk, c0, okv);
 #pragma unroll
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
 
   int n, d0, h0, w0;
   decode(t_begin, n, d0, h0, w0);
-  load_B(n, d0, h0, w0, 0);
+  load_B(-1, n, d0, h0, w0, 0);
   load_A(0);
   store_B();
   store_A(0);
@@ -305,28 +305,30 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
 #pragma unroll 1
     for (int p = 0; p < P; ++p, buf ^= 1) {
       const int chunk = p / 3, kd = p - chunk * 3;
-      const bool last_of_chunk = kd == 2;
-      const bool next_chunk = last_of_chunk && (chunk + 1 < a.NCH);
-      const bool next_tile = last_of_chunk && !next_chunk && more_tiles;
+      const bool last_chunk = chunk + 1 == a.NCH;
+      // the halo tile of the next chunk / of chunk 0 of the next tile is fetched during this chunk: half of the loads
+      // behind the MFMAs of phase kd 0, half behind those of kd 1 (all 16 loads in one 54-MFMA phase stretched it from
+      // 2.6 k to 8-10 k cycles: s_memtime stamps, tools/x2_stamps.py), split and stored after kd 2
+      const bool stage = !last_chunk || more_tiles;
+      const bool next_tile = last_chunk && more_tiles;
       X2_MARK(0);
       // slab p+1 (in registers since the previous phase) -> the buffer phase p-1 used; then fetch slab p+2
       if (p + 1 < P || more_tiles) store_A(buf ^ 1);
       if (p + 2 < P || more_tiles) load_A(p + 2 < P ? p + 2 : p + 2 - P);
-      if (next_tile) decode(tile + t_step, nn, nd0, nh0, nw0);
-      const bool stage = next_chunk || next_tile;  // fetch the halo tile of the next chunk / chunk 0 of the next tile
+      if (next_tile && kd == 0) decode(tile + t_step, nn, nd0, nh0, nw0);
       const char* ab = a_lds + buf * A_SLAB + lane * 16;
       const char* bb = b_lds + kd * (IH * IW * 16);
-      // The 9 taps of the slab with a register double buffer: the 9 ds_read_b128 of tap+1 go one per MFMA between
-      // the 12 MFMAs of tap, and in a staging phase the global loads of the next halo tile are spread over the taps
-      // as well (all issued up front they fill the CU's memory queue and the waves sit in the issue stage for
-      // microseconds with the matrix pipe idle).  sched_group_barrier pins the order; left alone, hipcc issues each
-      // LDS read right before its first use and waits on it.
-      auto phase = [&](auto STAGE) __attribute__((always_inline)) {
-        constexpr bool ST = decltype(STAGE)::value;
-        constexpr int NLD = VEC ? 2 : 5;  // global loads per tap (8 taps): 16 / 40 per thread
-        if constexpr (ST) {
+      // The 9 taps of the slab with a register double buffer: the 6 ds_read_b128 of tap+1 go one per MFMA between
+      // the 6 MFMAs of tap, and the global loads of a staging part are spread over the taps as well (all issued up
+      // front they fill the CU's memory queue and the waves sit in the issue stage for microseconds with the matrix
+      // pipe idle).  sched_group_barrier pins the order; left alone, hipcc issues each LDS read right before its first
+      // use and waits on it.
+      auto phase = [&](auto PART) __attribute__((always_inline)) {
+        constexpr int LD = decltype(PART)::value;        // -1: no loads, 0 / 1: staging part
+        constexpr int NLD = LD < 0 ? 0 : (VEC ? 1 : (LD == 0 ? 3 : 2));  // global loads per tap (8 taps)
+        if constexpr (LD >= 0) {
           const bool nt = next_tile;
-          load_B(nt ? nn : n, nt ? nd0 : d0, nt ? nh0 : h0, nt ? nw0 : w0, nt ? 0 : chunk + 1);
+          load_B(LD, nt ? nn : n, nt ? nd0 : d0, nt ? nh0 : h0, nt ? nw0 : w0, nt ? 0 : chunk + 1);
         }
         f16x8 fa[2][NT], fb[2][2][NT];
         auto load_frag = [&](int tap9, int slot) __attribute__((always_inline)) {
@@ -356,15 +358,17 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
             for (int i = 0; i < 6; ++i) {
               __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
               __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-              if (ST && i < NLD) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+              if (i < NLD) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
           }
         }
       };
       X2_MARK(1);
-      if (stage) phase(std::true_type{}); else phase(std::false_type{});
+      if (stage && kd == 0) phase(std::integral_constant<int, 0>{});
+      else if (stage && kd == 1) phase(std::integral_constant<int, 1>{});
+      else phase(std::integral_constant<int, -1>{});
       X2_MARK(2);
-      if (stage) {
+      if (stage && kd == 2) {
         __syncthreads();  // every wave is done reading the halo tile of this chunk
         X2_MARK(3);
         store_B();
@@ -469,7 +473,7 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
   }
   if (a.y_amax) {   // the consumer's operand maximum, for the next f16x2 convolution (order-independent atomicMax)
     y_am = wave_max(y_am);
-    if (lane == 0 && y_am > 0.f) atomicMax(a.y_amax, __float_as_uint(y_am));
+    if (lane == 0) dca_amax_put(a.y_amax, y_am, blockIdx.x * 8 + wv);
   }
 }
 
@@ -518,8 +522,7 @@ __global__ void x2_prep_weight_kernel(const float* __restrict__ src, unsigned sh
   }
 }
 
-// max |x| over a tensor as the bit pattern of an fp32 number: atomicMax on the unsigned patterns of |x| (monotonic for
-// non-negative floats) is order independent, so the result is bitwise reproducible.  The word must be zero beforehand.
+// max |x| over a tensor into the DCA_AMAX_SLOTS words of `out` (dca_common.h; zero beforehand)
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long n, int vec, unsigned* __restrict__ out) {
   float m = 0.f;
   const long stride = (long)gridDim.x * 256;
@@ -534,17 +537,17 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) m = fmaxf(m, fabsf(x[i]));
   }
   m = wave_max(m);
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+  if ((threadIdx.x & 63) == 0) dca_amax_put(out, m, blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 
 }  // namespace
 
-// word <- bit pattern of max |x[0..n)| (fp32): the operand maximum the f16x2 kernels scale by.  Two stream operations
-// (a 4-byte memset and one read pass); producers that know their output's maximum write the word themselves
-// (dca_bn_apply_amax, dca_bn_backward_amax).
+// word[DCA_AMAX_SLOTS] <- max |x[0..n)| (its fp32 bit pattern is the maximum over the words): the operand maximum the
+// f16x2 kernels scale by.  Two stream operations (a 256-byte memset and one read pass); producers that know their output's
+// maximum fill the words themselves (dca_bn_apply, dca_bn_backward, dca_conv3d_x2_forward).
 extern "C" int dca_amax_f32(const float* x, long n, unsigned* word, hipStream_t stream) {
   DCA_REQUIRE(x && word && n > 0);
-  hipError_t e = hipMemsetAsync(word, 0, 4, stream);
+  hipError_t e = hipMemsetAsync(word, 0, 4 * DCA_AMAX_SLOTS, stream);
   if (e != hipSuccess) return (int)e;
   const int vec = (((uintptr_t)x) & 15) == 0;
   long blocks = (n / 4 + 255) / 256;

@@ -67,7 +67,7 @@ struct WX2Args {
   float* part;
   int N, Cx, Cy, D, H, W;
   int nTD, nTH, nTW, nCxT;
-  const unsigned* x_amax;   // bit patterns of max |x| / max |dy| (fp32), device words
+  const unsigned* x_amax;   // max |x| / max |dy|: DCA_AMAX_SLOTS device words each (dca_common.h)
   const unsigned* y_amax;
 };
 
@@ -76,14 +76,6 @@ __device__ __forceinline__ void split2(float v, float s, _Float16& h, _Float16& 
   h = (_Float16)u;
   l = (_Float16)(u - (float)h);   // the residual is exact in fp32
 }
-// as in conv3d_f16x2.hip
-__device__ __forceinline__ int x2_scale_exp(unsigned bits) {
-  const int e = (int)((bits >> 23) & 255);
-  int ex = e == 0 ? 0 : 141 - e;
-  ex = ex > 60 ? 60 : (ex < -100 ? -100 : ex);
-  return ex;
-}
-__device__ __forceinline__ float x2_pow2(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
 
 __global__ __launch_bounds__(512) void wgrad3_f16x2_kernel(WX2Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -104,8 +96,8 @@ __global__ __launch_bounds__(512) void wgrad3_f16x2_kernel(WX2Args a) {
 
   const int cstride = a.D * a.H * a.W;
   const long xsample = (long)a.Cx * cstride, ysample = (long)a.Cy * cstride;
-  const int xexp = x2_scale_exp(__builtin_amdgcn_readfirstlane(*a.x_amax));
-  const int yexp = x2_scale_exp(__builtin_amdgcn_readfirstlane(*a.y_amax));
+  const int xexp = x2_scale_exp(dca_amax_get(a.x_amax));
+  const int yexp = x2_scale_exp(dca_amax_get(a.y_amax));
   const float xs = x2_pow2(xexp), ys = x2_pow2(yexp);
 
   // staging items: channel fastest (conflict-free LDS writes), then k half / side, then row

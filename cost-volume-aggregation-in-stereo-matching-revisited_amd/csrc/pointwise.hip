@@ -131,8 +131,7 @@ __global__ __launch_bounds__(64) void bn_finalize_centered_kernel(const double* 
 
 // The f16x2 convolution kernels (conv3d_f16x2.hip) scale their operands by a power of two taken from the tensor's max |.|;
 // the kernels that PRODUCE those operands (bn_apply: activations, bn_bwd_apply: gradients) emit it on the way: one
-// atomicMax per workgroup on the unsigned bit pattern of max |v| (monotonic for non-negative floats, order independent:
-// bitwise reproducible).  `amax` is a zero-initialised device word or null.
+// atomicMax per workgroup into one of the DCA_AMAX_SLOTS words of `amax` (dca_common.h; zero-initialised, or null).
 __device__ __forceinline__ void amax_emit(float m, unsigned* amax) {
   m = wave_max(m);
   __shared__ float amax_red[16];
@@ -142,7 +141,7 @@ __device__ __forceinline__ void amax_emit(float m, unsigned* amax) {
   if (threadIdx.x == 0) {
     const int nw = (blockDim.x + 63) >> 6;
     for (int i = 1; i < nw; ++i) m = fmaxf(m, amax_red[i]);
-    if (m > 0.f) atomicMax(amax, __float_as_uint(m));
+    dca_amax_put(amax, m, blockIdx.x);
   }
 }
 

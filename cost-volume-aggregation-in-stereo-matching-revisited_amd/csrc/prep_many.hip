@@ -24,14 +24,6 @@ __device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l)
   l = (__bf16)r2;
 }
 
-// as in conv3d_f16x2.hip
-__device__ __forceinline__ int x2_scale_exp(unsigned bits) {
-  const int e = (int)((bits >> 23) & 255);
-  int ex = e == 0 ? 0 : 141 - e;
-  ex = ex > 60 ? 60 : (ex < -100 ? -100 : ex);
-  return ex;
-}
-__device__ __forceinline__ float x2_pow2(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
 
 // stage 1 of the kind-3 entries: {2^ew, 2^-ew, max |w|, 0} behind the packed image (x2_weight_scale_kernel)
 __global__ __launch_bounds__(1024) void prep_many_scale_kernel(const PrepDesc* __restrict__ table) {

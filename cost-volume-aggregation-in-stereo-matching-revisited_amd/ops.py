@@ -298,13 +298,15 @@ _X3_MIN_WORKGROUPS = 1
 
 
 # ---- operand maxima for the f16x2 kernels -----------------------------------------------------------------------------
-# A "word" is a one-element int32 view holding the bit pattern of max |t| as an fp32 number.  Kernels that produce a
-# convolution operand emit it (BatchNorm apply / backward, the f16x2 convolution's own epilogue); it rides on the tensor
-# object as `_dca_amax = (word, t._version)` (an in-place change of t invalidates it).  Tensors without one get a read pass
-# (dca_amax_f32).  Words come from zero-filled pools and are used once; a pool allocated outside a stream capture is never
-# handed out inside one (a captured graph must zero its own words on every replay).
+# A "word" is a view of AMAX_SLOTS int32 (DCA_AMAX_SLOTS of include/dca_hip.h): the maximum over them is the bit pattern of
+# max |t| as an fp32 number.  Kernels that produce a convolution operand fill it (BatchNorm apply / backward, the f16x2
+# convolution's own epilogue); it rides on the tensor object as `_dca_amax = (word, t._version)` (an in-place change of t
+# invalidates it).  Tensors without one get a read pass (dca_amax_f32).  Words come from zero-filled pools and are used
+# once; a pool allocated outside a stream capture is never handed out inside one (a captured graph must zero its own words
+# on every replay).
 AMAX_STATS = {"tagged": 0, "computed": 0}
-_AMAX_POOL_WORDS = 4096
+AMAX_SLOTS = 64
+_AMAX_POOL_WORDS = 512
 
 
 def _amax_word(device):
@@ -312,11 +314,11 @@ def _amax_word(device):
     pool = getattr(_tls, "amax_pool", None)
     if pool is None or pool[1] >= _AMAX_POOL_WORDS or pool[2] != cap or pool[0].device != device or \
             pool[3] != torch.cuda.current_stream(device):
-        pool = _tls.amax_pool = [torch.zeros((_AMAX_POOL_WORDS,), device=device, dtype=torch.int32), 0, cap,
+        pool = _tls.amax_pool = [torch.zeros((_AMAX_POOL_WORDS * AMAX_SLOTS,), device=device, dtype=torch.int32), 0, cap,
                                  torch.cuda.current_stream(device)]
     i = pool[1]
     pool[1] = i + 1
-    return pool[0][i:i + 1]
+    return pool[0][i * AMAX_SLOTS:(i + 1) * AMAX_SLOTS]
 
 
 def _tag_amax(t, word):
@@ -331,7 +333,7 @@ def _amax_of(t):
         AMAX_STATS["tagged"] += 1
         return tag[0]
     AMAX_STATS["computed"] += 1
-    word = torch.empty((1,), device=t.device, dtype=torch.int32)
+    word = torch.empty((AMAX_SLOTS,), device=t.device, dtype=torch.int32)
     _chk(_L().dca_amax_f32(_ptr(t), t.numel(), _ptr(word), _stream()), "dca_amax_f32")
     _tag_amax(t, word)
     return word

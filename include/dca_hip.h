@@ -194,14 +194,19 @@ int dca_conv3d_wgrad_x3(const float* x, const float* dy, float* part, float* dw,
  * accumulation; the result is scaled back in the epilogue.  Half the matrix-pipe cycles of the bf16x3 kernels at the
  * same measured error against fp64.  Same operators as dca_conv3d_x3_forward / dca_conv3d_wgrad_x3
  * (models/submodule.py:121-124, models/augment/cva.py:13-55) and, with src_ab = 1 / flip = 1, their backward-data.
- *   dca_amax_f32: word <- bit pattern of max |x[0..n)| as an fp32 number (a memset and one read pass); the BatchNorm
- *       kernels emit the same word for the tensors they write (dca_bn_apply / dca_bn_backward, `amax`).
+ *   Operand maxima: a tensor's max |.| is passed as DCA_AMAX_SLOTS (64) device words; every workgroup of the producing
+ *       kernel folds its maximum into one of them by atomicMax on the unsigned bit pattern of the non-negative fp32 number
+ *       (monotonic: order independent, bitwise reproducible; 64 slots because thousands of atomics on one address
+ *       serialise), the consumer takes the maximum over the words.  Producers need ZERO-initialised words.
+ *   dca_amax_f32: words <- max |x[0..n)| (a 256-byte memset and one read pass); the BatchNorm kernels fill the same words
+ *       for the tensors they write (dca_bn_apply / dca_bn_backward, `amax`).
  *   dca_conv3d_x2_weight_bytes / dca_conv3d_x2_prep_weight: packed image (fragments, then {2^ew, 2^-ew, max |w|, 0});
  *       argument meaning of dca_conv3d_x3_prep_weight.
- *   dca_conv3d_x2_forward[_stats]: contracts of dca_conv3d_x3_forward[_stats]; x_amax = the operand's word; y_amax (may be
- *       null) = zero-initialised word that receives max |y| for the next convolution.
+ *   dca_conv3d_x2_forward[_stats]: contracts of dca_conv3d_x3_forward[_stats]; x_amax = the operand's words; y_amax (may
+ *       be null) = zero-initialised words that receive max |y| for the next convolution.
  *   dca_conv3d_wgrad_x2: contract of dca_conv3d_wgrad_x3; x_amax / y_amax = the words of x and dy. */
-int dca_amax_f32(const float* x, long n, unsigned* word, hipStream_t stream);
+#define DCA_AMAX_SLOTS 64
+int dca_amax_f32(const float* x, long n, unsigned* words, hipStream_t stream);
 long dca_conv3d_x2_weight_bytes(int Cin, int Cout);
 int dca_conv3d_x2_prep_weight(const float* w, void* wx, int A, int B, int src_ab, int flip, hipStream_t stream);
 int dca_conv3d_x2_forward(const float* x, const unsigned* x_amax, const void* wx, float* y, const float* scale,
@@ -235,9 +240,9 @@ int dca_conv3d_c1_bwd_data(const float* dy, const float* w, float* dx, int N, in
  * dca_bn_apply:    z = act(scale*y + shift + res_pre) + res_post.
  * dca_bn_backward: given dz -> dy (grad of the conv output), dgb = [dgamma | dbeta | ...] (4*C floats),
  *                  optional g_out = grad w.r.t. res_pre (= dz masked by the activation).
- * amax (dca_bn_apply: of z, dca_bn_backward: of dy; may be null): a ZERO-initialised device word that receives the bit
- *                  pattern of max |.| of the tensor written, as an fp32 number -- the operand maximum the f16x2
- *                  convolution kernels below scale by (order-independent atomicMax on unsigned patterns). */
+ * amax (dca_bn_apply: of z, dca_bn_backward: of dy; may be null): DCA_AMAX_SLOTS ZERO-initialised device words that receive
+ *                  max |.| of the tensor written (see "f16x2" above) -- the operand maximum the f16x2 convolution
+ *                  kernels scale by. */
 int dca_bn_num_chunks(int C, long S);
 int dca_bn_stats(const float* x, double* part, int N, int C, long S, hipStream_t stream);
 int dca_bn_finalize(const double* part, int nchunk, double count, const float* gamma, const float* beta,

@@ -24,10 +24,12 @@ gb = N * C * S * 4 / 1e9
 s = ops._stream
 us = t(lambda: ops._chk(L.dca_bn_stats(ops._ptr(y), ops._ptr(part), N, C, S, s()), "stats"))
 print("N=%d bn_stats    %.0f us  %.2f TB/s" % (N, us, gb / us * 1e3))
-us = t(lambda: ops._chk(L.dca_bn_apply(ops._ptr(y), ops._ptr(stats), None, None, ops._ptr(z), N, C, S, 0.0, s()), "apply"))
-print("N=%d bn_apply    %.0f us  %.2f TB/s" % (N, us, 2 * gb / us * 1e3))
-us = t(lambda: ops._chk(L.dca_bn_backward(ops._ptr(dz), ops._ptr(y), None, ops._ptr(stats), ops._ptr(part), ops._ptr(dgb), ops._ptr(dy), None, N, C, S, 0.0, 1, s()), "bwd"))
-print("N=%d bn_backward %.0f us  %.2f TB/s (reduce 2 reads + apply 2 reads 1 write)" % (N, us, 5 * gb / us * 1e3))
+am = torch.zeros(ops.AMAX_SLOTS, dtype=torch.int32, device=dev)
+for word, tag in ((None, ""), (am, " + max |.| words")):
+    us = t(lambda: ops._chk(L.dca_bn_apply(ops._ptr(y), ops._ptr(stats), None, None, ops._ptr(z), N, C, S, 0.0, ops._ptr(word), s()), "apply"))
+    print("N=%d bn_apply%s    %.0f us  %.2f TB/s" % (N, tag, us, 2 * gb / us * 1e3))
+    us = t(lambda: ops._chk(L.dca_bn_backward(ops._ptr(dz), ops._ptr(y), None, ops._ptr(stats), ops._ptr(part), ops._ptr(dgb), ops._ptr(dy), None, N, C, S, 0.0, 1, ops._ptr(word), s()), "bwd"))
+    print("N=%d bn_backward%s %.0f us  %.2f TB/s (reduce 2 reads + apply 2 reads 1 write)" % (N, tag, us, 5 * gb / us * 1e3))
 a = torch.empty_like(y)
 us = t(lambda: torch.add(y, dz, out=a))
 print("N=%d torch add   %.0f us  %.2f TB/s" % (N, us, 3 * gb / us * 1e3))

@@ -81,5 +81,5 @@ for (N, cx, cy, d, h, w) in [(1, 32, 32, 48, 136, 240), (4, 32, 32, 48, 136, 240
             line.append("%s fwd %.1f us wgrad %.1f us" % (f, t(lambda: conv(x, wt)), t(lambda: wgrad(x, dy))))
     print("N=%d %d->%d @%dx%dx%d: %s" % (N, cx, cy, d, h, w, " | ".join(line)), flush=True)
 x = torch.randn(4, 32, 48, 136, 240, device=dev)
-word = torch.empty(1, dtype=torch.int32, device=dev)
+word = torch.empty(ops.AMAX_SLOTS, dtype=torch.int32, device=dev)
 print("dca_amax_f32 over 4x32x48x136x240: %.1f us" % t(lambda: ops._chk(ops._L().dca_amax_f32(ops._ptr(x), x.numel(), ops._ptr(word), ops._stream()), "amax")))
