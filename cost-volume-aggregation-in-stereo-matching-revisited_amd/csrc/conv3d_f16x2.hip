@@ -153,7 +153,7 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
   const __amdgpu_buffer_rsrc_t wr = dca_rsrc((const char*)a.wx + (long)cblk * wbytes, wbytes);
   const int xexp = x2_scale_exp(dca_amax_get(a.x_amax));
   const float xs = x2_pow2(xexp);                        // operand scale
-  const float inv = x2_pow2(-xexp) * a.wtail[1];         // accumulator -> fp32 result
+  const float inv = x2_pow2(-xexp) * dca_coherent_loadf(a.wtail + 1);   // accumulator -> fp32 result
 
 #if X2_STAMP
   unsigned long long* stamps = (unsigned long long*)a.res_post;
@@ -471,9 +471,9 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
     __syncthreads();
     fs_flush(stat_lds, 8, tid, cblk * 32, a.Cout, a.stat_part, gridDim.x, blockIdx.x);
   }
-  if (a.y_amax) {   // the consumer's operand maximum, for the next f16x2 convolution (order-independent atomicMax)
+  if (a.y_amax) {   // the consumer's operand maximum, for the next f16x2 convolution: one slot per wave
     y_am = wave_max(y_am);
-    if (lane == 0) dca_amax_put(a.y_amax, y_am, blockIdx.x * 8 + wv);
+    if (lane == 0) dca_amax_put(a.y_amax, y_am, (blockIdx.y * gridDim.x + blockIdx.x) * 8 + wv);
   }
 }
 
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(1024) void x2_weight_scale_kernel(const float* __re
 
 __global__ void x2_prep_weight_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int A, int Bn,
                                       int NCH, int src_ab, int flip, long total) {
-  const float ws = ((const float*)(dst + total))[0];
+  const float ws = dca_coherent_loadf((const float*)(dst + total));   // written by x2_weight_scale_kernel just before
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int j = idx & 7, lane = (idx >> 3) & 63;
     long t = idx >> 9;
@@ -522,7 +522,10 @@ __global__ void x2_prep_weight_kernel(const float* __restrict__ src, unsigned sh
   }
 }
 
-// max |x| over a tensor into the DCA_AMAX_SLOTS words of `out` (dca_common.h; zero beforehand)
+// zero-fill of the DCA_AMAX_SLOTS words (a kernel: one node type in captured graphs)
+__global__ void amax_zero_kernel(unsigned* __restrict__ out) { out[blockIdx.x * 256 + threadIdx.x] = 0u; }
+
+// max |x| over a tensor into the DCA_AMAX_SLOTS words of `out` (dca_common.h; zero beforehand): one slot per wave
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long n, int vec, unsigned* __restrict__ out) {
   float m = 0.f;
   const long stride = (long)gridDim.x * 256;
@@ -537,21 +540,20 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) m = fmaxf(m, fabsf(x[i]));
   }
   m = wave_max(m);
-  if ((threadIdx.x & 63) == 0) dca_amax_put(out, m, blockIdx.x * 4 + (threadIdx.x >> 6));
+  if ((threadIdx.x & 63) == 0) dca_amax_put(out, m, blockIdx.x * 4 + (threadIdx.x >> 6));   // grid <= DCA_AMAX_SLOTS / 4
 }
 
 }  // namespace
 
 // word[DCA_AMAX_SLOTS] <- max |x[0..n)| (its fp32 bit pattern is the maximum over the words): the operand maximum the
-// f16x2 kernels scale by.  Two stream operations (a 256-byte memset and one read pass); producers that know their output's
+// f16x2 kernels scale by.  Two launches (zero fill of the 32 KB and one read pass); producers that know their output's
 // maximum fill the words themselves (dca_bn_apply, dca_bn_backward, dca_conv3d_x2_forward).
 extern "C" int dca_amax_f32(const float* x, long n, unsigned* word, hipStream_t stream) {
   DCA_REQUIRE(x && word && n > 0);
-  hipError_t e = hipMemsetAsync(word, 0, 4 * DCA_AMAX_SLOTS, stream);
-  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(amax_zero_kernel, dim3(DCA_AMAX_SLOTS / 256), dim3(256), 0, stream, word);
   const int vec = (((uintptr_t)x) & 15) == 0;
   long blocks = (n / 4 + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > DCA_AMAX_SLOTS / 4) blocks = DCA_AMAX_SLOTS / 4;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(amax_kernel, dim3((int)blocks), dim3(256), 0, stream, x, n, vec, word);
   return dca_launch_status();
@@ -619,6 +621,7 @@ int x2_launch(const float* x, const unsigned* x_amax, const void* wx, float* y, 
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return (int)e;
   const int cblks = (Cout + 31) / 32;
+  DCA_REQUIRE(y_amax == nullptr || (long)x2_grid(tiles, cblks) * cblks * 8 <= DCA_AMAX_SLOTS);   // one slot per wave
   hipLaunchKernelGGL(kern, dim3(x2_grid(tiles, cblks), cblks), dim3(512), lds, stream, a);
   return dca_launch_status();
 }

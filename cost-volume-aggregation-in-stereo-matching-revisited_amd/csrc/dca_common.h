@@ -95,25 +95,45 @@ __device__ __forceinline__ float4 dca_bload4(__amdgpu_buffer_rsrc_t r, int byte_
 }
 
 // ---- operand maxima of the f16x2 kernels (conv3d_f16x2.hip) --------------------------------------------------------------
-// A tensor's max |.| travels as DCA_AMAX_SLOTS zero-initialised device words: every workgroup of the producing kernel
-// folds its own maximum into ONE slot (atomicMax on the unsigned bit pattern of a non-negative fp32 number: monotonic, so
-// order independent and bitwise reproducible); the consumer takes the maximum over the slots.  One word for all
-// workgroups serialises thousands of atomics on one address (measured: +45 us on a 150 us BatchNorm pass).
+// A tensor's max |.| travels as DCA_AMAX_SLOTS zero-initialised device words: every workgroup (or wave) of the producing
+// kernel STORES the bit pattern of its own maximum (a non-negative fp32 number, so unsigned order = float order) into a
+// slot of its own, and the consuming workgroup takes the maximum over all slots.  Plain stores and loads only:
+//  * atomicMax on ONE word serialised thousands of atomics on one address (+45 us on a 150 us BatchNorm pass);
+//  * atomicMax spread over 64 words was fast and correct in eager launches, but inside hipGraph replays the second and
+//    later replays of a graph read wrong maxima (a graph of [zero-fill, amax kernel, convolution] alone reproduced it:
+//    tools/x2_graph_debug4.py) -- the words were right after the replay, the convolution had seen something else.
 #ifndef DCA_AMAX_SLOTS
-#define DCA_AMAX_SLOTS 64
+#define DCA_AMAX_SLOTS 8192
 #endif
-__device__ __forceinline__ void dca_amax_put(unsigned* amax, float m, int slot_seed) {
-  if (m > 0.f) atomicMax(amax + (slot_seed & (DCA_AMAX_SLOTS - 1)), __float_as_uint(m));
-}
-// wave-uniform maximum over the slots (call with all 64 lanes active)
+// slot must be < DCA_AMAX_SLOTS and owned by the caller (one writer per slot and launch)
+__device__ __forceinline__ void dca_amax_put(unsigned* amax, float m, int slot) { amax[slot] = __float_as_uint(m); }
+// maximum over the slots, uniform over the workgroup; EVERY thread of the workgroup must call it (barriers inside)
 __device__ __forceinline__ unsigned dca_amax_get(const unsigned* amax) {
-  unsigned v = amax[threadIdx.x & (DCA_AMAX_SLOTS - 1)];
+  __shared__ unsigned dca_amax_red[16];
+  const int nthr = blockDim.x * blockDim.y * blockDim.z, tid = threadIdx.x;
+  unsigned v = 0;
+  for (int i = tid * 4; i < DCA_AMAX_SLOTS; i += nthr * 4) {
+    const uint4 q = *(const uint4*)(amax + i);
+    const unsigned a = q.x > q.y ? q.x : q.y, b = q.z > q.w ? q.z : q.w, m = a > b ? a : b;
+    v = v > m ? v : m;
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const unsigned w = (unsigned)__shfl_xor((int)v, o, 64);
     v = v > w ? v : w;
   }
+  if ((tid & 63) == 0) dca_amax_red[tid >> 6] = v;
+  __syncthreads();
+  const int nw = (nthr + 63) >> 6;
+  v = dca_amax_red[0];
+  for (int i = 1; i < nw; ++i) v = v > dca_amax_red[i] ? v : dca_amax_red[i];
+  __syncthreads();   // the array may be reused by the next call
   return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+// a value another kernel wrote shortly before (the scale tail of a packed weight image), read with a device-coherent
+// vector load instead of an s_load through the scalar data cache
+__device__ __forceinline__ float dca_coherent_loadf(const float* p) {
+  return __uint_as_float(__hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 // power of two that brings a tensor whose max |.| has the bit pattern `bits` into [2^14, 2^15); 1 for an all-zero tensor.
 // The exponent is clamped to [-100, 60]: beyond that the data are fp32 denormals / infinities and nothing is to be kept.

@@ -130,8 +130,8 @@ __global__ __launch_bounds__(64) void bn_finalize_centered_kernel(const double* 
 }
 
 // The f16x2 convolution kernels (conv3d_f16x2.hip) scale their operands by a power of two taken from the tensor's max |.|;
-// the kernels that PRODUCE those operands (bn_apply: activations, bn_bwd_apply: gradients) emit it on the way: one
-// atomicMax per workgroup into one of the DCA_AMAX_SLOTS words of `amax` (dca_common.h; zero-initialised, or null).
+// the kernels that PRODUCE those operands (bn_apply: activations, bn_bwd_apply: gradients) emit it on the way: every
+// workgroup stores its maximum into its own slot of `amax` (DCA_AMAX_SLOTS words, dca_common.h; zero-initialised, or null).
 __device__ __forceinline__ void amax_emit(float m, unsigned* amax) {
   m = wave_max(m);
   __shared__ float amax_red[16];
@@ -141,7 +141,7 @@ __device__ __forceinline__ void amax_emit(float m, unsigned* amax) {
   if (threadIdx.x == 0) {
     const int nw = (blockDim.x + 63) >> 6;
     for (int i = 1; i < nw; ++i) m = fmaxf(m, amax_red[i]);
-    dca_amax_put(amax, m, blockIdx.x);
+    dca_amax_put(amax, m, blockIdx.x);      // ew_grid() <= DCA_AMAX_SLOTS workgroups
   }
 }
 
@@ -680,6 +680,7 @@ static int ew_grid(long total) {
   long g = (total + 255) / 256;
   return (int)(g < 8192 ? (g > 0 ? g : 1) : 8192);
 }
+static_assert(DCA_AMAX_SLOTS >= 8192, "bn_apply / bn_bwd_apply: one operand-maximum slot per workgroup");
 
 static void chunking(long S, int C, int* nchunk, long* chunk_len) {
   // enough blocks to fill 256 CUs a few times over, chunks a multiple of 1024 floats

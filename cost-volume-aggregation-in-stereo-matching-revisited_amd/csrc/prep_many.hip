@@ -49,7 +49,7 @@ __global__ __launch_bounds__(1024) void prep_many_scale_kernel(const PrepDesc* _
 
 __global__ __launch_bounds__(256) void prep_many_kernel(const PrepDesc* __restrict__ table) {
   const PrepDesc d = table[blockIdx.y];
-  const float ws = d.kind == 3 ? ((const float*)((const unsigned short*)d.dst + d.total))[0] : 1.f;
+  const float ws = d.kind == 3 ? dca_coherent_loadf((const float*)((const unsigned short*)d.dst + d.total)) : 1.f;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < d.total; idx += (long)gridDim.x * 256) {
     if (d.kind == 0) {
       const int ab = d.Apad * d.Bpad;

@@ -305,11 +305,14 @@ _X3_MIN_WORKGROUPS = 1
 # once; a pool allocated outside a stream capture is never handed out inside one (a captured graph must zero its own words
 # on every replay).
 AMAX_STATS = {"tagged": 0, "computed": 0}
-AMAX_SLOTS = 64
-_AMAX_POOL_WORDS = 512
+AMAX_SLOTS = 8192
+_AMAX_POOL_WORDS = 64
+AMAX_EMIT = os.environ.get("DCA_AMAX_EMIT", "1") != "0"    # 0: no producer-side maxima, every operand gets its read pass (A/B)
 
 
 def _amax_word(device):
+    if not AMAX_EMIT:
+        return None
     cap = torch.cuda.is_current_stream_capturing()
     pool = getattr(_tls, "amax_pool", None)
     if pool is None or pool[1] >= _AMAX_POOL_WORDS or pool[2] != cap or pool[0].device != device or \

@@ -194,18 +194,18 @@ int dca_conv3d_wgrad_x3(const float* x, const float* dy, float* part, float* dw,
  * accumulation; the result is scaled back in the epilogue.  Half the matrix-pipe cycles of the bf16x3 kernels at the
  * same measured error against fp64.  Same operators as dca_conv3d_x3_forward / dca_conv3d_wgrad_x3
  * (models/submodule.py:121-124, models/augment/cva.py:13-55) and, with src_ab = 1 / flip = 1, their backward-data.
- *   Operand maxima: a tensor's max |.| is passed as DCA_AMAX_SLOTS (64) device words; every workgroup of the producing
- *       kernel folds its maximum into one of them by atomicMax on the unsigned bit pattern of the non-negative fp32 number
- *       (monotonic: order independent, bitwise reproducible; 64 slots because thousands of atomics on one address
- *       serialise), the consumer takes the maximum over the words.  Producers need ZERO-initialised words.
- *   dca_amax_f32: words <- max |x[0..n)| (a 256-byte memset and one read pass); the BatchNorm kernels fill the same words
+ *   Operand maxima: a tensor's max |.| is passed as DCA_AMAX_SLOTS (8192) device words; every workgroup (or wave) of the
+ *       producing kernel stores the bit pattern of its own maximum (a non-negative fp32 number) into a slot of its own, the
+ *       consumer takes the unsigned maximum over all words.  No atomics (bitwise reproducible; and atomicMax-filled words
+ *       were read wrongly inside hipGraph replays).  Producers need ZERO-initialised words.
+ *   dca_amax_f32: words <- max |x[0..n)| (a 32 KB zero fill and one read pass); the BatchNorm kernels fill the same words
  *       for the tensors they write (dca_bn_apply / dca_bn_backward, `amax`).
  *   dca_conv3d_x2_weight_bytes / dca_conv3d_x2_prep_weight: packed image (fragments, then {2^ew, 2^-ew, max |w|, 0});
  *       argument meaning of dca_conv3d_x3_prep_weight.
  *   dca_conv3d_x2_forward[_stats]: contracts of dca_conv3d_x3_forward[_stats]; x_amax = the operand's words; y_amax (may
  *       be null) = zero-initialised words that receive max |y| for the next convolution.
  *   dca_conv3d_wgrad_x2: contract of dca_conv3d_wgrad_x3; x_amax / y_amax = the words of x and dy. */
-#define DCA_AMAX_SLOTS 64
+#define DCA_AMAX_SLOTS 8192
 int dca_amax_f32(const float* x, long n, unsigned* words, hipStream_t stream);
 long dca_conv3d_x2_weight_bytes(int Cin, int Cout);
 int dca_conv3d_x2_prep_weight(const float* w, void* wx, int A, int B, int src_ab, int flip, hipStream_t stream);
