@@ -47,6 +47,11 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #ifndef X2_STAMP
 #define X2_STAMP 0
 #endif
+// X2_LD_FRONT (A/B builds): 1 = the staging loads of a phase in one burst in front of the slab stores, 2 = two per tap
+// behind the first four taps, 0 (shipped) = one per tap
+#ifndef X2_LD_FRONT
+#define X2_LD_FRONT 0
+#endif
 #if X2_STAMP
 #define X2_MARK(i) do { if (stamp_on && stamp_k < 96) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) stamps[stamp_k * 8 + (i)] = t_; } } while (0)
 #else
@@ -312,10 +317,20 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
       const bool stage = !last_chunk || more_tiles;
       const bool next_tile = last_chunk && more_tiles;
       X2_MARK(0);
+#if X2_LD_FRONT == 1
+      // the staging part's global loads in front of the slab stores: the matrix pipe is idle there anyway
+      if (stage && kd < 2) {
+        const bool nt = next_tile;
+        if (nt && kd == 0) decode(tile + t_step, nn, nd0, nh0, nw0);
+        load_B(kd, nt ? nn : n, nt ? nd0 : d0, nt ? nh0 : h0, nt ? nw0 : w0, nt ? 0 : chunk + 1);
+      }
+#endif
       // slab p+1 (in registers since the previous phase) -> the buffer phase p-1 used; then fetch slab p+2
       if (p + 1 < P || more_tiles) store_A(buf ^ 1);
       if (p + 2 < P || more_tiles) load_A(p + 2 < P ? p + 2 : p + 2 - P);
+#if X2_LD_FRONT != 1
       if (next_tile && kd == 0) decode(tile + t_step, nn, nd0, nh0, nw0);
+#endif
       const char* ab = a_lds + buf * A_SLAB + lane * 16;
       const char* bb = b_lds + kd * (IH * IW * 16);
       // The 9 taps of the slab with a register double buffer: the 6 ds_read_b128 of tap+1 go one per MFMA between
@@ -358,15 +373,19 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
             for (int i = 0; i < 6; ++i) {
               __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
               __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-              if (i < NLD) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+              if (i < (X2_LD_FRONT == 2 ? (tap9 < 4 ? 2 * NLD : 0) : NLD)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
           }
         }
       };
       X2_MARK(1);
+#if X2_LD_FRONT == 1
+      phase(std::integral_constant<int, -1>{});
+#else
       if (stage && kd == 0) phase(std::integral_constant<int, 0>{});
       else if (stage && kd == 1) phase(std::integral_constant<int, 1>{});
       else phase(std::integral_constant<int, -1>{});
+#endif
       X2_MARK(2);
       if (stage && kd == 2) {
         __syncthreads();  // every wave is done reading the halo tile of this chunk

@@ -477,6 +477,59 @@ def test_conv3d_bf16x3_fused_epilogue(fam, monkeypatch):
         assert word == y.abs().max().item(), (word, y.abs().max().item())
 
 
+@pytest.mark.parametrize("mag", [1e-12, 1.0, 3e4], ids=["1e-12", "1", "3e4"])
+def test_conv3d_f16x2_any_magnitude(mag, monkeypatch):
+    """the f16x2 kernels scale their operands by a power of two from the tensor's max |.|, so the f16 range restricts
+    nothing: activations of 3e4 (beyond f16's 65504 after any accumulation) and loss gradients of 1e-12 (below f16's
+    smallest subnormal) give the same RELATIVE error against fp64 as O(1) data -- forward, backward-data, weight gradient"""
+    _, ops = _mods()
+    _family(monkeypatch, ops, "f16x2")
+    N, cin, cout, dims = 1, 32, 32, (5, 9, 20)
+    x = seeded_tensor("x2m.x", (N, cin) + dims) * mag; w = seeded_tensor("x2m.w", (cout, cin, 3, 3, 3)) * 0.05
+    gy = seeded_tensor("x2m.g", (N, cout) + dims) * (mag ** -0.5 if mag > 1 else mag)
+    xd, wd = x.double().requires_grad_(), w.double().requires_grad_()
+    yr = F.conv3d(xd, wd, None, 1, 1)
+    gxr, gwr = torch.autograd.grad((yr * gy.double()).sum(), [xd, wd])
+    xg, wg = gpu(x, True), gpu(w, True)
+    y = ops.conv3d(xg, wg, 1, False)
+    gx, gw = torch.autograd.grad((y * gy.to(DEV)).sum(), [xg, wg])
+    for got, ref, name in ((y, yr, "fwd"), (gx, gxr, "dx"), (gw, gwr, "dw")):
+        err = (got.detach().cpu().double() - ref.detach()).abs().max().item()
+        assert torch.isfinite(got).all(), name
+        assert err <= 2e-6 * ref.abs().max().item(), (name, mag, err, ref.abs().max().item())
+
+
+def test_f16x2_producer_maxima_equal_read_pass(monkeypatch):
+    """the operand maxima the BatchNorm kernels / the convolution epilogue emit are exactly the tensor's max |.|, so a
+    training step (conv -> BN -> ReLU -> conv, backward) gives BITWISE the same result with producer-side maxima as with
+    a read pass per operand (DCA_AMAX_EMIT=0)"""
+    _, ops = _mods()
+    import torch.nn as nn
+    _family(monkeypatch, ops, "f16x2")
+    c1 = nn.Conv3d(32, 32, 3, 1, 1, bias=False).to(DEV); b1 = nn.BatchNorm3d(32).to(DEV)
+    c2 = nn.Conv3d(32, 32, 3, 1, 1, bias=False).to(DEV); b2 = nn.BatchNorm3d(32).to(DEV)
+    x = seeded_tensor("x2p.x", (2, 32, 6, 10, 24)).to(DEV)
+    gz = seeded_tensor("x2p.g", (2, 32, 6, 10, 24)).to(DEV) * 1e-6
+    res = {}
+    for emit in (True, False):
+        monkeypatch.setattr(ops, "AMAX_EMIT", emit)
+        for b in (b1, b2):
+            b.reset_running_stats()
+        before = dict(ops.AMAX_STATS)
+        xx = x.clone().requires_grad_()
+        z = ops.convbn3d(ops.convbn3d(xx, c1, b1, 0.0), c2, b2, 0.0, res_post=xx)
+        g = torch.autograd.grad((z * gz).sum(), [xx, c1.weight, c2.weight, b1.weight])
+        res[emit] = [z.detach()] + [t.detach() for t in g]
+        used = {k: ops.AMAX_STATS[k] - before[k] for k in before}
+        if emit:
+            assert used["tagged"] >= 4, used      # z1 (forward + weight gradient), dy2, dy1 came with their tensors
+        else:
+            assert used["computed"] >= 4, used    # x, z1, dy2, dy1: one read pass each
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
+    assert torch.isfinite(res[True][1]).all() and res[True][1].abs().max() > 0
+
+
 def test_frozen_weights_cache_is_exact_and_scoped():
     """ops.frozen_weights(): cached weight re-layouts / BN folds give bit-identical results, are reused inside the
     context, and are dropped (weights may change again) outside it"""

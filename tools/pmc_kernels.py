@@ -22,6 +22,8 @@ sys.path.insert(0, ROOT)
 
 V4 = 48 * 136 * 240
 KEYS = {   # substring of the kernel name -> (key, algorithmic bytes per launch)
+    "::conv3_f16x2_kernel": ("conv3_f16x2", 2 * 32 * V4 * 4 + 27 * 32 * 32 * 4),
+    "wgrad3_f16x2_kernel": ("wgrad3_f16x2", 2 * 32 * V4 * 4 + 27 * 32 * 32 * 4),
     "::conv3_bf16x3_kernel": ("conv3_bf16x3", 2 * 32 * V4 * 4 + 27 * 32 * 32 * 4),
     "wgrad3_bf16x3_kernel": ("wgrad3_bf16x3", 2 * 32 * V4 * 4 + 27 * 32 * 32 * 4),
     "conv3_mfma_kernel<1, 1, 8, 4, 8, 16, true": ("conv3_mfma", 2 * 32 * V4 * 4 + 27 * 32 * 32 * 4),
