@@ -47,7 +47,10 @@ int dca_internal_wgrad_reduce(const float* part, float* dw, int nblk, int nCxT, 
 namespace {
 
 constexpr int NT = 2;                                 // terms per operand
-constexpr int TD = 2, TH = 4, TW = 16;
+#ifndef WX2_TH
+#define WX2_TH 4
+#endif
+constexpr int TD = 2, TH = WX2_TH, TW = 16;
 constexpr int NROW = TD * TH;                       // 8 K-steps (output rows) per tile
 constexpr int HD = TD + 2, HH = TH + 2, NHROW = HD * HH;  // 24 halo rows
 constexpr int X_TERM = NHROW * 2 * 32 * 16;         // bytes of one term image of x: [hrow][k half][ci][8 f16]
