@@ -12,9 +12,11 @@
 // fp64 convolutions the kernel measures the same error as the fp32 MFMA kernel (the fp32 accumulation of 27*Cin products
 // dominates both), tests/test_gpu_parity.py.
 //
-// The operand maxima arrive as device words (bit pattern of max |x| as an fp32 number): the kernels that produce the
-// operands emit them (bn_apply / bn_bwd_apply, pointwise.hip) or dca_amax_f32 computes them; the weight's power of two is
-// chosen by the weight packing kernel and stored behind the packed image.  Nothing is read back by the host.
+// The operand maxima arrive as DCA_AMAX_SLOTS device words per tensor (dca_common.h: one slot per producing workgroup /
+// wave, each the bit pattern of a partial max |x| as an fp32 number; the consumer takes the maximum over the slots): the
+// kernels that produce the operands fill them (bn_apply / bn_bwd_apply, pointwise.hip; this kernel's own epilogue) or
+// dca_amax_f32 computes them; the weight's power of two is chosen by the weight packing kernel and stored behind the
+// packed image.  Nothing is read back by the host; no atomics.
 //
 // Reference operators served: nn.Conv3d(k=3, s=1, p=1) of convbn_3d (models/submodule.py:121-124) in dres0/dres1,
 // Multi_Aggregation and the cva blocks (models/augment/cva.py:13-55), and their backward-data.
@@ -33,7 +35,7 @@
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-// Non-temporal output stores (X2_NT=1): y is written once, so it need not displace the halo lines the neighbouring tiles
+// Non-temporal output stores (X2_NT=1; measured on the bf16x3 kernel, whose epilogue this is): y is written once, so it need not displace the halo lines the neighbouring tiles
 // re-read from this XCD's L2 -- 591 -> 568 us on the fused-epilogue 32->32 launch at 48x136x240 in isolation
 // (tools/nt_ablate.sh).  In the network the consumer of y (BatchNorm statistics + apply in training, the next convolution
 // in inference) runs right behind and finds a 200 MB output partly in the 256 MB infinity cache when it was stored with
