@@ -110,7 +110,9 @@ __device__ __forceinline__ void split2(float v, float s, _Float16& h, _Float16& 
 // the partial statistics {K, n, sum (y - K), sum (y - K)^2} that dca_bn_finalize_centered consumes (bn_fused_stats.h), so the
 // 200 MB statistics pass over y disappears.  Per tile: 3 vector instructions per output value, a DPP reduction over the 32
 // positions of a wave half, one ds_add_f32 per (half, channel) into a wave-private LDS slot.
-template <bool VEC, bool STATS>
+// EPI = false: no affine / residual / activation epilogue (the training-mode launches: forward with BatchNorm statistics,
+// backward-data) -- the epilogue's arrays, descriptors and branches are compiled out
+template <bool VEC, bool STATS, bool EPI>
 __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* b_lds = smem;
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
   const bool stamp_on = blockIdx.x == 0 && blockIdx.y == 0 && wv == 0;
   int stamp_k = 0;
 #endif
-  const bool has_aff = a.scale != nullptr, has_pre = a.res_pre != nullptr, has_post = a.res_post != nullptr;
+  const bool has_aff = EPI && a.scale != nullptr, has_pre = EPI && a.res_pre != nullptr, has_post = EPI && a.res_post != nullptr;
   float4 ra[KA];
   auto load_A = [&](int p) __attribute__((always_inline)) {
 #pragma unroll
@@ -411,12 +413,14 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
     const __amdgpu_buffer_rsrc_t yr = dca_rsrc(a.y + (long)n * osample, osample * 4);
     const __amdgpu_buffer_rsrc_t pr = dca_rsrc((has_pre ? a.res_pre : a.y) + (long)n * osample, osample * 4);
     const __amdgpu_buffer_rsrc_t qr = dca_rsrc((has_post ? a.res_post : a.y) + (long)n * osample, osample * 4);
-    float sc[16], sh[16];  // (re)loaded per tile: holding them across the MFMA phases costs 32 registers
+    float sc[EPI ? 16 : 1], sh[EPI ? 16 : 1];  // (re)loaded per tile: holding them across the MFMA phases costs 32 registers
+    if constexpr (EPI) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = min(cblk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, a.Cout - 1);
-      sc[r] = (has_aff ? a.scale[co] : 1.f) * inv;
-      sh[r] = has_aff ? a.shift[co] : 0.f;
+      for (int r = 0; r < 16; ++r) {
+        const int co = min(cblk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, a.Cout - 1);
+        sc[r] = (has_aff ? a.scale[co] : 1.f) * inv;
+        sh[r] = has_aff ? a.shift[co] : 0.f;
+      }
     }
     float st_s[STATS ? 16 : 1], st_q[STATS ? 16 : 1], st_n = 0.f;
     if constexpr (STATS) {
@@ -447,10 +451,15 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int cu = (r & 3) + 8 * (r >> 2);
-        float v = acc[t][r] * sc[r] + sh[r];
-        if (has_pre) v += rp[r];
-        v = act_apply(v, a.slope);
-        if (has_post) v += rq[r];
+        float v;
+        if constexpr (EPI) {
+          v = acc[t][r] * sc[r] + sh[r];
+          if (has_pre) v += rp[r];
+          v = act_apply(v, a.slope);
+          if (has_post) v += rq[r];
+        } else {
+          v = acc[t][r] * inv;
+        }
         if constexpr (STATS) {
           if (stat_first && t == 0) {   // the wave's first tile: the shift of (half, r) = what lane 0 of the half produced
             const float kf = fs_half_first(v, half);
@@ -636,8 +645,11 @@ int x2_launch(const float* x, const unsigned* x_amax, const void* wx, float* y, 
   DCA_REQUIRE(tiles < 0x7fffffffL && (Cout + 31) / 32 <= 65535);
   const bool vec = (W % 4 == 0) && ((((uintptr_t)x) & 15) == 0);
   const bool stats = stat_part != nullptr;
-  auto kern = stats ? (vec ? conv3_f16x2_kernel<true, true> : conv3_f16x2_kernel<false, true>)
-                    : (vec ? conv3_f16x2_kernel<true, false> : conv3_f16x2_kernel<false, false>);
+  const bool epi = scale != nullptr || res_pre != nullptr || res_post != nullptr || slope != 1.f;
+  DCA_REQUIRE(!(stats && epi));    // the statistics are those of the raw convolution output
+  auto kern = stats ? (vec ? conv3_f16x2_kernel<true, true, false> : conv3_f16x2_kernel<false, true, false>)
+              : epi ? (vec ? conv3_f16x2_kernel<true, false, true> : conv3_f16x2_kernel<false, false, true>)
+                    : (vec ? conv3_f16x2_kernel<true, false, false> : conv3_f16x2_kernel<false, false, false>);
   const int lds = LDS_BYTES + (stats ? STAT_LDS : 0);
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return (int)e;
