@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(HERE, "libdca_hip.so")
 
 _p, _i, _l, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double
 
-ABI_VERSION = 10  # == DCA_ABI_VERSION of include/dca_hip.h
+ABI_VERSION = 11  # == DCA_ABI_VERSION of include/dca_hip.h
 
 # name -> (restype, argtypes); mirrors include/dca_hip.h one to one
 SIGNATURES = {
@@ -49,6 +49,8 @@ SIGNATURES = {
     "dca_conv3d_x2_stats_chunks": (_l, [_i] * 5),
     "dca_conv3d_x2_forward_stats": (_i, [_p] * 5 + [_i] * 6 + [_p]),
     "dca_conv3d_wgrad_x2_workspace": (_l, [_i] * 6),
+    "dca_conv3d_wgrad_s2_x2_workspace": (_l, [_i] * 6),
+    "dca_conv3d_wgrad_s2_x2": (_i, [_p] * 6 + [_i] * 6 + [_l, _l, _p]),
     "dca_conv3d_wgrad_x2": (_i, [_p] * 6 + [_i] * 6 + [_l, _l, _p]),
     "dca_conv3d_wgrad": (_i, [_p, _p, _p, _p] + [_i] * 11 + [_l, _l, _p]),
     "dca_conv3d_c1_gather": (_i, [_p, _p, _i, _i, _i, _i, _p]),

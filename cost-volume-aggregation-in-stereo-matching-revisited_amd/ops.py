@@ -292,6 +292,7 @@ def _round_up(a, m):
 _CONV_MODE = os.environ.get("DCA_CONV", "x2")
 CONV_X3 = _CONV_MODE != "fp32"
 CONV_X2 = _CONV_MODE == "x2"
+WGRAD_S2_X2 = os.environ.get("DCA_WGRAD_S2", "x2") != "fp32"   # stride-2 / transposed weight gradient on the f16x2 split (A/B)
 DECONV_X3 = os.environ.get("DCA_DECONV", "x3") != "fp32"
 BN_FUSE = os.environ.get("DCA_BN_FUSE", "1") != "0"        # BatchNorm batch statistics from the conv epilogue (training)   # the transposed-convolution member of the family alone (A/B timing)
 _X3_MIN_WORKGROUPS = 1
@@ -569,6 +570,17 @@ def _wgrad(x, dy, dw_view_ptr_tensor, dst_offset, Cx, Cy, ksize, stride, s_cy, s
         part = torch.empty((nws,), device=x.device, dtype=torch.float32)
         _chk(lib.dca_conv3d_wgrad_x3(_ptr(x), _ptr(dy), _ptr(part), dst, N, Cx, Cy, Di, Hi, Wi, s_cy, s_cx, _stream()),
              "dca_conv3d_wgrad_x3")
+        return
+    if (CONV_X2 and CONV_X3 and WGRAD_S2_X2 and ksize == 3 and stride == 2 and Wi % 4 == 0 and Wo % 4 == 0
+            and (Do, Ho, Wo) == ((Di + 1) // 2, (Hi + 1) // 2, (Wi + 1) // 2)
+            and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0 and max(Cx, Cy) * Di * Hi * Wi * 4 < 0x7ffffff0):
+        # stride-2 convolution / transposed convolution: x = the fine tensor, dy = the coarse one (conv3d_wgrad_s2_f16x2.hip)
+        xam = x_amax if x_amax is not None else _amax_of(x)
+        yam = y_amax if y_amax is not None else _amax_of(dy)
+        nws = lib.dca_conv3d_wgrad_s2_x2_workspace(N, Cx, Cy, Di, Hi, Wi)
+        part = torch.empty((nws,), device=x.device, dtype=torch.float32)
+        _chk(lib.dca_conv3d_wgrad_s2_x2(_ptr(x), _ptr(xam), _ptr(dy), _ptr(yam), _ptr(part), dst, N, Cx, Cy, Di, Hi, Wi,
+                                        s_cy, s_cx, _stream()), "dca_conv3d_wgrad_s2_x2")
         return
     nws = lib.dca_conv3d_wgrad_workspace(N, Cx, Cy, Do, Ho, Wo, ksize, stride)
     part = torch.empty((nws,), device=x.device, dtype=torch.float32)

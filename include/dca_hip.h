@@ -23,7 +23,7 @@ extern "C" {
 
 /* Bumped whenever an argument list below changes; the ctypes loader (_lib.py) refuses a library built from another
  * version of this header. */
-#define DCA_ABI_VERSION 10
+#define DCA_ABI_VERSION 11
 int dca_abi_version(void);
 
 /* storage types of the reduced-precision inference path (0 = fp32) */
@@ -215,6 +215,14 @@ int dca_conv3d_x2_forward(const float* x, const unsigned* x_amax, const void* wx
 long dca_conv3d_x2_stats_chunks(int N, int Cout, int D, int H, int W);
 int dca_conv3d_x2_forward_stats(const float* x, const unsigned* x_amax, const void* wx, float* y, double* stat_part,
                                 int N, int Cin, int Cout, int D, int H, int W, hipStream_t stream);
+/* dca_conv3d_wgrad_s2_x2: the same arithmetic for the weight gradient of the STRIDE-2 convolution `cost_agg.conv1` and of
+ * the transposed convolution `cost_agg.conv3` (models/augment/cva.py:16-29; conv3d_wgrad_s2_f16x2.hip):
+ * dw[cy*s_cy + cx*s_cx + tap] = sum_{n,o} c[n][cy][o] * f[n][cx][2o + tap - 1], f = fine tensor (N,Cx,D,H,W), c = coarse tensor
+ * (N,Cy,(D+1)/2,(H+1)/2,(W+1)/2); for the transposed convolution f = dy, c = x.  Requires W % 4 == 0, (W+1)/2 % 4 == 0 and
+ * 16-byte aligned tensors (hipErrorInvalidValue otherwise: callers use dca_conv3d_wgrad). */
+long dca_conv3d_wgrad_s2_x2_workspace(int N, int Cx, int Cy, int D, int H, int W);
+int dca_conv3d_wgrad_s2_x2(const float* f, const unsigned* f_amax, const float* c, const unsigned* c_amax, float* part,
+                           float* dw, int N, int Cx, int Cy, int D, int H, int W, long s_cy, long s_cx, hipStream_t stream);
 long dca_conv3d_wgrad_x2_workspace(int N, int Cx, int Cy, int D, int H, int W);
 int dca_conv3d_wgrad_x2(const float* x, const unsigned* x_amax, const float* dy, const unsigned* y_amax, float* part,
                         float* dw, int N, int Cx, int Cy, int D, int H, int W, long s_cy, long s_cx, hipStream_t stream);

@@ -123,8 +123,8 @@ SPLIT_FAMILIES = ["bf16x3", "f16x2"]
 
 def _family(monkeypatch, ops, fam):
     """conv kernel family: fp32mfma = fp32 MFMA kernels everywhere; bf16x3 = the three-term bf16 split kernels;
-    f16x2 (shipped default) = the two-term f16 split kernels for the 3x3x3 stride-1 convolution and its weight gradient,
-    bf16x3 for the transposed / 1x1x1 members"""
+    f16x2 (shipped default) = the two-term f16 split kernels for the 3x3x3 stride-1 convolution, its weight gradient and
+    the stride-2 / transposed weight gradient, bf16x3 for the transposed / 1x1x1 forward members"""
     monkeypatch.setattr(ops, "CONV_X3", fam != "fp32mfma")
     monkeypatch.setattr(ops, "CONV_X2", fam == "f16x2")
 
@@ -164,8 +164,6 @@ def test_conv3d(case, fam, monkeypatch):
     if x3 and not (case[2] == 3 and case[1] > 1):
         pytest.skip("bf16x3 kernels: 3x3x3 stride-1 convolutions, transposed convolutions (<= 32 output channels) and the "
                     "backward-data of the stride-2 ones; the 1x1x1 kernel has its own test")
-    if fam == "f16x2" and (case[3] != 1 or case[4]):
-        pytest.skip("f16x2 kernels: 3x3x3 stride-1 convolutions only")
     cin, cout, k, stride, transposed, dims, N = case
     x = seeded_tensor(f"cv.x{case}", (N, cin) + dims)
     wshape = (cin, cout, k, k, k) if transposed else (cout, cin, k, k, k)
@@ -456,6 +454,43 @@ def test_wgrad_bf16x3(case, fam, monkeypatch):
     assert e3 <= 1.5 * e32 + 1e-7 * ref.abs().max().item(), (e3, e32)
     close_l2(g3, ref.float(), 1e-6, "dw")
     assert torch.equal(g3, run(True))
+
+
+WS2_CASES = [
+    # N, cx (fine channels), cy (coarse channels), fine dims   (W % 4 == 0 and (W+1)//2 % 4 == 0)
+    (1, 32, 64, (4, 8, 40)),
+    (2, 32, 64, (8, 12, 72)),
+    (1, 32, 33, (5, 9, 24)),        # odd fine D / H, partial channel block
+    (3, 20, 64, (2, 6, 8)),
+    (1, 64, 32, (6, 18, 136)),      # several W tiles, the last one partial
+]
+
+
+@pytest.mark.parametrize("case", WS2_CASES, ids=str)
+def test_wgrad_s2_f16x2(case, monkeypatch):
+    """weight gradient of the stride-2 convolution (= of the transposed convolution with the tensors' roles exchanged) on
+    the f16x2 split kernel (conv3d_wgrad_s2_f16x2.hip) against fp64: at least as accurate as the fp32 MFMA kernel, bitwise
+    reproducible, and any magnitude of the operands"""
+    _, ops = _mods()
+    N, cx, cy, dims = case
+    cdims = tuple((d + 1) // 2 for d in dims)
+    for mag_x, mag_y in ((1.0, 1.0), (1e3, 1e-9)):
+        x = seeded_tensor(f"ws2.x{case}", (N, cx) + dims) * mag_x
+        dy = seeded_tensor(f"ws2.g{case}", (N, cy) + cdims) * mag_y
+        ref = torch.nn.grad.conv3d_weight(x.double(), (cy, cx, 3, 3, 3), dy.double(), stride=2, padding=1)
+        xg, dyg = x.to(DEV), dy.to(DEV)
+
+        def run(on):
+            _family(monkeypatch, ops, "f16x2")
+            monkeypatch.setattr(ops, "WGRAD_S2_X2", on)
+            gw = torch.empty(cy, cx, 3, 3, 3, device=DEV)
+            ops._wgrad(xg, dyg, gw, 0, cx, cy, 3, 2, cx * 27, 27)
+            return gw
+        g2, g32 = run(True), run(False)
+        e2, e32 = (g2.cpu().double() - ref).abs().max().item(), (g32.cpu().double() - ref).abs().max().item()
+        assert e2 <= 1.5 * e32 + 2e-7 * ref.abs().max().item(), (e2, e32, ref.abs().max().item())
+        close_l2(g2, ref.float(), 1e-6, "dw")
+        assert torch.equal(g2, run(True))
 
 
 @pytest.mark.parametrize("fam", SPLIT_FAMILIES)
