@@ -122,8 +122,10 @@ __global__ __launch_bounds__(512) void wgrad3s2_f16x2_kernel(WS2Args a) {
       const int ok = (int)(it < NX_ITEMS) & (int)(cx0 + c < a.Cx) & (int)((unsigned)d < (unsigned)a.D) &
                      (int)((unsigned)h < (unsigned)a.H);
       const int off = ((cx0 + c) * cstride + (d * a.H + h) * a.W + w) * 4;
+      if (512 * k + (tid & ~63) < NX_ITEMS) {   // wave-uniform: the last item round has work for three waves only
 #pragma unroll
-      for (int q = 0; q < 4; ++q) rx[k][q] = dca_bload4(xr, off + 16 * q, ok & (int)(w + 4 * q + 3 < a.W));   // W % 4 == 0
+        for (int q = 0; q < 4; ++q) rx[k][q] = dca_bload4(xr, off + 16 * q, ok & (int)(w + 4 * q + 3 < a.W));   // W % 4 == 0
+      }
     }
 #pragma unroll
     for (int k = 0; k < KE; ++k) {
@@ -131,9 +133,9 @@ __global__ __launch_bounds__(512) void wgrad3s2_f16x2_kernel(WS2Args a) {
       const int d = 2 * d0 - 1 + frow / FH, h = 2 * h0 - 1 + frow % FH, w = 2 * w0 - 1;
       const int ok = (int)(it < NE_ITEMS) & (int)(cx0 + c < a.Cx) & (int)((unsigned)d < (unsigned)a.D) &
                      (int)((unsigned)h < (unsigned)a.H) & (int)((unsigned)w < (unsigned)a.W);
-      re[k] = dca_bload1(xr, ((cx0 + c) * cstride + (d * a.H + h) * a.W + w) * 4, ok);
+      if (512 * k + (tid & ~63) < NE_ITEMS) re[k] = dca_bload1(xr, ((cx0 + c) * cstride + (d * a.H + h) * a.W + w) * 4, ok);
     }
-    {
+    if ((tid & ~63) < NY_ITEMS) {
       const int c = tid & 31, hf = (tid >> 5) & 1, row = tid >> 6;
       const int h = h0 + row, w = w0 + 8 * hf;
       const int ok = (int)(tid < NY_ITEMS) & (int)(cy0 + c < a.Cy) & (int)(h < a.Ho);
