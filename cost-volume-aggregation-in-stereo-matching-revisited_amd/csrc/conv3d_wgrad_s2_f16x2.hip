@@ -37,6 +37,11 @@ int dca_internal_wgrad_reduce(const float* part, float* dw, int nblk, int nCxT, 
 #ifndef WX2_STAMP
 #define WX2_STAMP 0
 #endif
+// WS2_SPLIT_LOADS: the next tile's loads in two portions, behind the first and the second K-step (batch 4, 32->64 at
+// 48x136x240: 842 -> 785 us; all of them in front of the MFMA phase: 908 us)
+#ifndef WS2_SPLIT_LOADS
+#define WS2_SPLIT_LOADS 1
+#endif
 #ifndef WX2_LOADS_IN
 #define WX2_LOADS_IN 1
 #endif
@@ -112,11 +117,13 @@ __global__ __launch_bounds__(512) void wgrad3s2_f16x2_kernel(WS2Args a) {
     n = tile / a.nTD;
     d0 = td; h0 = th * TH; w0 = tw * TW;            // coarse coordinates
   };
-  auto load_tile = [&](int n, int d0, int h0, int w0) __attribute__((always_inline)) {
+  // part 0: the first two rounds of fine items, part 1: the rest (fine items, edge voxels, coarse rows), part -1: all
+  auto load_tile = [&](int n, int d0, int h0, int w0, int part = -1) __attribute__((always_inline)) {
     const __amdgpu_buffer_rsrc_t xr = dca_rsrc(a.x + (long)n * xsample, xsample * 4);
     const __amdgpu_buffer_rsrc_t yr = dca_rsrc(a.dy + (long)n * ysample, ysample * 4);
 #pragma unroll
     for (int k = 0; k < KX; ++k) {   // 16 consecutive fine voxels from 2 w0 + 16 hf: the 8 even and 8 odd ones of a k half
+      if ((part == 0 && k >= 2) || (part == 1 && k < 2)) continue;
       const int it = tid + 512 * k, c = it & 31, hf = (it >> 5) & 1, frow = it >> 6;
       const int d = 2 * d0 - 1 + frow / FH, h = 2 * h0 - 1 + frow % FH, w = 2 * w0 + 16 * hf;
       const int ok = (int)(it < NX_ITEMS) & (int)(cx0 + c < a.Cx) & (int)((unsigned)d < (unsigned)a.D) &
@@ -127,6 +134,7 @@ __global__ __launch_bounds__(512) void wgrad3s2_f16x2_kernel(WS2Args a) {
         for (int q = 0; q < 4; ++q) rx[k][q] = dca_bload4(xr, off + 16 * q, ok & (int)(w + 4 * q + 3 < a.W));   // W % 4 == 0
       }
     }
+    if (part != 0) {
 #pragma unroll
     for (int k = 0; k < KE; ++k) {
       const int it = tid + 512 * k, c = it & 31, frow = it >> 5;
@@ -142,6 +150,7 @@ __global__ __launch_bounds__(512) void wgrad3s2_f16x2_kernel(WS2Args a) {
       const int off = ((cy0 + c) * ystride + (d0 * a.Ho + h) * a.Wo + w) * 4;
       ry[0] = dca_bload4(yr, off, ok & (int)(w + 3 < a.Wo));        // Wo % 4 == 0
       ry[1] = dca_bload4(yr, off + 16, ok & (int)(w + 7 < a.Wo));
+    }
     }
   };
   auto split_store8 = [&](const float (&v)[8], float sc, char* base, int term_stride, int off) __attribute__((always_inline)) {
@@ -193,11 +202,19 @@ __global__ __launch_bounds__(512) void wgrad3s2_f16x2_kernel(WS2Args a) {
     constexpr int R0 = TAP0 / 3, R1 = (TAP1 - 1) / 3;  // (kd, kh) rows this wave touches
 #pragma unroll 1
     for (int i = 0; i < NROW; ++i) {
+#if WS2_SPLIT_LOADS
+      if (WX2_LOADS_IN && (i == 1 || i == 2) && more) {
+        int nn, nd0, nh0, nw0;
+        decode(next_tile, nn, nd0, nh0, nw0);
+        load_tile(nn, nd0, nh0, nw0, i - 1);
+      }
+#else
       if (WX2_LOADS_IN && i == 1 && more) {
         int nn, nd0, nh0, nw0;
         decode(next_tile, nn, nd0, nh0, nw0);
         load_tile(nn, nd0, nh0, nw0);
       }
+#endif
       const int row = i;                             // coarse h row of the tile (one coarse d plane per tile)
       f16x8 ay[NT];
 #pragma unroll
