@@ -47,8 +47,15 @@ int dca_internal_wgrad_reduce(const float* part, float* dw, int nblk, int nCxT, 
 namespace {
 
 constexpr int NT = 2;                                 // terms per operand
+// WX2_G8 (A/B): eight tap groups of 3-4 taps, every wave runs all K-steps of the tile (64 accumulator registers, no
+// cross-group reduction) instead of two K-step groups x four tap groups of 7 (112); with it the 2 x 8 x 16 tile fits
+// without spills (216 registers) -- measured slower: 1308 us (2 x 8 x 16) / 1344 us (2 x 4 x 16) against 1246 us at 32->32,
+// 48x136x240, batch 4: every wave then builds the shifted fragments of its tap rows for ALL K-steps
+#ifndef WX2_G8
+#define WX2_G8 0
+#endif
 #ifndef WX2_TH
-#define WX2_TH 4
+#define WX2_TH (WX2_G8 ? 8 : 4)
 #endif
 constexpr int TD = 2, TH = WX2_TH, TW = 16;
 constexpr int NROW = TD * TH;                       // 8 K-steps (output rows) per tile
@@ -83,7 +90,13 @@ __device__ __forceinline__ void split2(float v, float s, _Float16& h, _Float16& 
 __global__ __launch_bounds__(512) void wgrad3_f16x2_kernel(WX2Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, half = lane >> 5;
+#if WX2_G8
+  const int grp = 0, wq = wv;
+  constexpr int NACC = 4, NGRP = 1;
+#else
   const int grp = wv >> 2, wq = wv & 3;
+  constexpr int NACC = 7, NGRP = 2;
+#endif
   const int ct = blockIdx.y, cy0 = (ct / a.nCxT) * 32, cx0 = (ct % a.nCxT) * 32;
 
   const long T = (long)a.N * a.nTD * a.nTH * a.nTW;
@@ -91,9 +104,9 @@ __global__ __launch_bounds__(512) void wgrad3_f16x2_kernel(WX2Args a) {
   const int cnt = (gridDim.x - xcd + nx - 1) / nx;
   const int t_begin = (int)(T * xcd / nx) + blockIdx.x / nx, t_end = (int)(T * (xcd + 1) / nx), t_step = cnt;
 
-  f32x16 acc[7];
+  f32x16 acc[NACC];
 #pragma unroll
-  for (int j = 0; j < 7; ++j)
+  for (int j = 0; j < NACC; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
@@ -178,16 +191,20 @@ __global__ __launch_bounds__(512) void wgrad3_f16x2_kernel(WX2Args a) {
   // cycles (s_memtime stamps, tools/wx3_stamps.py).
   auto mfma_tile = [&](auto WQC, bool more, int next_tile) __attribute__((always_inline)) {
     constexpr int WQ = decltype(WQC)::value;
+#if WX2_G8
+    constexpr int TAP0 = 27 * WQ / 8, TAP1 = 27 * (WQ + 1) / 8;
+#else
     constexpr int TAP0 = 7 * WQ, TAP1 = (TAP0 + 7 < 27) ? TAP0 + 7 : 27;
+#endif
     constexpr int R0 = TAP0 / 3, R1 = (TAP1 - 1) / 3;  // (kd, kh) rows this wave touches
 #pragma unroll 1
-    for (int i = 0; i < NROW / 2; ++i) {
+    for (int i = 0; i < NROW / NGRP; ++i) {
       if (WX2_LOADS_IN && i == 1 && more) {
         int nn, nd0, nh0, nw0;
         decode(next_tile, nn, nd0, nh0, nw0);
         load_tile(nn, nd0, nh0, nw0);
       }
-      const int row = grp * (NROW / 2) + i, dl = row / TH, hl = row % TH;
+      const int row = grp * (NROW / NGRP) + i, dl = row / TH, hl = row % TH;
       f16x8 ay[NT];
 #pragma unroll
       for (int term = 0; term < NT; ++term)
@@ -260,7 +277,15 @@ __global__ __launch_bounds__(512) void wgrad3_f16x2_kernel(WX2Args a) {
         case 0: mfma_tile(std::integral_constant<int, 0>{}, more, tile + t_step); break;
         case 1: mfma_tile(std::integral_constant<int, 1>{}, more, tile + t_step); break;
         case 2: mfma_tile(std::integral_constant<int, 2>{}, more, tile + t_step); break;
+#if WX2_G8
+        case 3: mfma_tile(std::integral_constant<int, 3>{}, more, tile + t_step); break;
+        case 4: mfma_tile(std::integral_constant<int, 4>{}, more, tile + t_step); break;
+        case 5: mfma_tile(std::integral_constant<int, 5>{}, more, tile + t_step); break;
+        case 6: mfma_tile(std::integral_constant<int, 6>{}, more, tile + t_step); break;
+        default: mfma_tile(std::integral_constant<int, 7>{}, more, tile + t_step); break;
+#else
         default: mfma_tile(std::integral_constant<int, 3>{}, more, tile + t_step); break;
+#endif
       }
       WX2_MARK(2);
       __syncthreads();  // every wave is done reading this tile
@@ -275,9 +300,25 @@ __global__ __launch_bounds__(512) void wgrad3_f16x2_kernel(WX2Args a) {
     }
   }
 
+  const float inv = x2_pow2(-xexp) * x2_pow2(-yexp);
+#if WX2_G8
+  {  // every wave writes the slab entries of its own taps: part[((blk*nCT + ct)*27 + tap)*1024 + co*32 + ci]
+    float* slab = a.part + ((long)blockIdx.x * gridDim.y + ct) * 27 * 1024;
+    const int tap0 = 27 * wq / 8, ntap = 27 * (wq + 1) / 8 - tap0;
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) {
+      if (j < ntap) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
+          slab[(tap0 + j) * 1024 + co * 32 + l31] = acc[j][r] * inv;
+        }
+      }
+    }
+  }
+#else
   // group 1 -> LDS, group 0 adds and writes the slab: part[((blk*nCT + ct)*27 + tap)*1024 + co*32 + ci]
   float* red = (float*)smem;  // [wq 4][j 7][co 32][ci 32]
-  const float inv = x2_pow2(-xexp) * x2_pow2(-yexp);
   if (grp == 1) {
 #pragma unroll
     for (int j = 0; j < 7; ++j)
@@ -300,6 +341,7 @@ __global__ __launch_bounds__(512) void wgrad3_f16x2_kernel(WX2Args a) {
       }
     }
   }
+#endif
 }
 
 int workers(long ntiles, int nCT) {
