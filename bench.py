@@ -185,6 +185,14 @@ def kernel_roofline(device, dtype="f32"):
                           "wgrad3_bf16x3", PEAK_BF16_MFMA_TFLOPS / 6.0, run_wgrad(True, False)))
         cases.append(("wgrad3_kernel<S1> (+reduce) (dW of 3x3x3 32->32 @1/4 res, fp32 MFMA)", "wgrad3",
                       PEAK_FP32_MFMA_TFLOPS, run_wgrad(False, False)))
+        # weight gradient of the stride-2 convolution / transposed convolution of the cva blocks (32 <-> 64 channels)
+        if ops.CONV_X3 and ops.CONV_X2 and ops.WGRAD_S2_X2:
+            xc2 = torch.randn(1, 64, d // 2, h // 2, w // 2, device=device)
+            gw2 = torch.empty(64, 32, 3, 3, 3, device=device)
+            cases.append(("wgrad3s2_f16x2_kernel (+reduce) (dW of the 3x3x3 stride-2 conv 32->64, 1/4 -> 1/8 res; 3-product f16 "
+                          "split)", "wgrad3s2_f16x2", PEAK_BF16_MFMA_TFLOPS / 3.0,
+                          lambda: ops._wgrad(x, xc2, gw2, 0, 32, 64, 3, 2, 32 * 27, 27),
+                          2.0 * 27 * 32 * 64 * (d // 2) * (h // 2) * (w // 2)))
         # the transposed convolution of the cva blocks (64 -> 32, 1/8 -> 1/4 res), same 6-product split: its own FLOP count
         if ops.CONV_X3 and ops.DECONV_X3:
             xc = torch.randn(1, 64, d // 2, h // 2, w // 2, device=device)
@@ -234,7 +242,7 @@ def kernel_roofline(device, dtype="f32"):
                 out[name]["algorithmic_bytes"] = lp_bytes
                 out[name]["hbm_view"] = {"achieved": round(lp_bytes / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
                                          "unit": "GB/s", "frac": round(lp_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
-            if key in ("conv3_f16x2", "wgrad3_f16x2"):
+            if key in ("conv3_f16x2", "wgrad3_f16x2", "wgrad3s2_f16x2"):
                 out[name]["peak_note"] = "dense f16 MFMA peak (2500) / 3 products per fp32 product"
                 out[name]["executed_f16"] = {"achieved": round(3 * tf, 1), "peak": PEAK_BF16_MFMA_TFLOPS,
                                              "unit": "TFLOP/s", "frac": round(3 * tf / PEAK_BF16_MFMA_TFLOPS, 4)}

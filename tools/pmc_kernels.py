@@ -24,6 +24,7 @@ V4 = 48 * 136 * 240
 KEYS = {   # substring of the kernel name -> (key, algorithmic bytes per launch)
     "::conv3_f16x2_kernel": ("conv3_f16x2", 2 * 32 * V4 * 4 + 27 * 32 * 32 * 4),
     "wgrad3_f16x2_kernel": ("wgrad3_f16x2", 2 * 32 * V4 * 4 + 27 * 32 * 32 * 4),
+    "wgrad3s2_f16x2_kernel": ("wgrad3s2_f16x2", 4 * (32 * V4 + 64 * V4 // 8) + 27 * 32 * 64 * 4),
     "::conv3_bf16x3_kernel": ("conv3_bf16x3", 2 * 32 * V4 * 4 + 27 * 32 * 32 * 4),
     "wgrad3_bf16x3_kernel": ("wgrad3_bf16x3", 2 * 32 * V4 * 4 + 27 * 32 * 32 * 4),
     "conv3_mfma_kernel<1, 1, 8, 4, 8, 16, true": ("conv3_mfma", 2 * 32 * V4 * 4 + 27 * 32 * 32 * 4),
