@@ -131,6 +131,13 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
   const int t_begin = (int)(T * xcd / nx) + blockIdx.x / nx, t_end = (int)(T * (xcd + 1) / nx), t_step = cnt;
   float* stat_w = stat_lds + wv * FS_WAVE_FLOATS;   // this wave's slots
   bool stat_first = true;
+  // STATS: per-lane running sums of (y - K) and (y - K)^2 over all tiles of the workgroup (the epilogue-free variants have
+  // the 32 registers to spare), reduced over the wave halves once, after the tile loop
+  float st_s[STATS ? 16 : 1], st_q[STATS ? 16 : 1], st_n = 0.f;
+  if constexpr (STATS) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st_s[r] = st_q[r] = 0.f;
+  }
   float y_am = 0.f;          // max |y| this lane has written (y_amax)
   if constexpr (STATS) {
     for (int i = tid; i < 8 * FS_WAVE_FLOATS; i += 512) stat_lds[i] = 0.f;
@@ -422,11 +429,6 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
         sh[r] = has_aff ? a.shift[co] : 0.f;
       }
     }
-    float st_s[STATS ? 16 : 1], st_q[STATS ? 16 : 1], st_n = 0.f;
-    if constexpr (STATS) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st_s[r] = st_q[r] = 0.f;
-    }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int r0 = (wv * 2 + t) * 2 + (l31 >> 4), d = d0 + (r0 >> 3), h = h0 + (r0 & 7), w = w0 + wlane;
@@ -478,19 +480,7 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
 #endif
       }
     }
-    if constexpr (STATS) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float rs = fs_half_sum(st_s[r]), rq2 = fs_half_sum(st_q[r]);
-        if ((lane & 31) == 0) {
-          atomicAdd(fs_slot(stat_w, half, r) + 1, rs);    // ds_add_f32 without return; wave-private slot, one writer lane
-          atomicAdd(fs_slot(stat_w, half, r) + 2, rq2);
-        }
-      }
-      const float rn = fs_half_sum(st_n);
-      if ((lane & 31) == 0) atomicAdd(stat_w + 96 + half, rn);
-      stat_first = false;
-    }
+    if constexpr (STATS) stat_first = false;
     X2_MARK(7);
 #if X2_STAMP
     ++stamp_k;
@@ -498,6 +488,16 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
     n = nn; d0 = nd0; h0 = nh0; w0 = nw0;
   }
   if constexpr (STATS) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float rs = fs_half_sum(st_s[r]), rq2 = fs_half_sum(st_q[r]);
+      if ((lane & 31) == 0) {   // wave-private slot, one writer lane
+        fs_slot(stat_w, half, r)[1] = rs;
+        fs_slot(stat_w, half, r)[2] = rq2;
+      }
+    }
+    const float rn = fs_half_sum(st_n);
+    if ((lane & 31) == 0) stat_w[96 + half] = rn;
     __syncthreads();
     fs_flush(stat_lds, 8, tid, cblk * 32, a.Cout, a.stat_part, gridDim.x, blockIdx.x);
   }
