@@ -50,5 +50,22 @@ for it in range(iters):
         print(f"{it:3d} N{N} {cin:3d}->{cout:3d} {D}x{H}x{W:3d} |x|~{mx:.0e} |gy|~{mg:.0e}: fwd {rel(y, yr):.1e} dx {rel(gx, gxr):.1e} "
               f"dw {rel(gw, gwr):.1e} epilogue {rel(ye, yer):.1e}{flag}", flush=True)
     assert ok
+# weight gradient of the stride-2 / transposed convolution (conv3d_wgrad_s2_f16x2.hip): fine W % 8 == 0
+for it in range(iters // 3):
+    N = random.choice([1, 2, 3]); cx = random.choice([3, 16, 20, 32, 40, 64]); cy = random.choice([8, 32, 33, 64, 100])
+    D, H, W = random.randint(1, 9), random.randint(1, 22), random.choice([8, 16, 24, 40, 64, 72, 136])
+    cd = tuple((v + 1) // 2 for v in (D, H, W))
+    x = torch.randn(N, cx, D, H, W, device=dev) * 10.0 ** random.uniform(-6, 3)
+    dy = torch.randn(N, cy, *cd, device=dev) * 10.0 ** random.uniform(-10, 1)
+    gw = torch.empty(cy, cx, 3, 3, 3, device=dev)
+    before = ops.AMAX_STATS["computed"]
+    ops._wgrad(x, dy, gw, 0, cx, cy, 3, 2, cx * 27, 27)
+    assert ops.AMAX_STATS["computed"] == before + 2, "the f16x2 stride-2 kernel was not taken"
+    ref = torch.nn.grad.conv3d_weight(x.double(), (cy, cx, 3, 3, 3), dy.double(), stride=2, padding=1)
+    e = rel(gw, ref)
+    worst = max(worst, e)
+    if e >= 1e-5 or not torch.isfinite(gw).all() or it % 10 == 9:
+        print(f"s2 {it:3d} N{N} {cx:3d}<->{cy:3d} fine {D}x{H}x{W:3d}: dw {e:.1e}" + ("" if e < 1e-5 else "   <-- CHECK"), flush=True)
+    assert torch.isfinite(gw).all()
 print("worst relative error", worst, "| maxima:", ops.AMAX_STATS)
 assert worst < 1e-5
