@@ -31,8 +31,10 @@ class Multi_Aggregation(nn.Module):
         self.redir = convbn_3d(in_channels, in_channels, kernel_size=1, stride=1, pad=0)
 
     def forward(self, x, res_post=None):
-        c2 = self.conv2(self.conv1(x))
-        skip = self.redir(x)
+        # conv1 (stride 2) and redir (1x1x1) read the same x: one autograd node, so their two gradients of x are summed in
+        # the second backward-data launch instead of by a separate accumulation pass (ops.convbn3d_pair)
+        c1, skip = ops.convbn3d_pair(x, self.conv1[0][0], self.conv1[0][1], 0.0, self.redir[0], self.redir[1], 1.0)
+        c2 = self.conv2(c1)
         # relu(conv3(c2) + redir(x)) [+ res_post, fused: the caller's `cost0 + augmented_cost`]
         return self.conv3(c2, slope=0.0, res_pre=skip, res_post=res_post)
 

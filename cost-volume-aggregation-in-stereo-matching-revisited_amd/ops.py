@@ -698,6 +698,65 @@ class _Conv3d(torch.autograd.Function):
         return gx, gx2, gw, None, None, None
 
 
+class _ConvPair(torch.autograd.Function):
+    """Two convolutions of ONE input -- A: 3x3x3 stride 2, B: 1x1x1 (`cost_agg.conv1` and `cost_agg.redir` of
+    Multi_Aggregation, models/augment/cva.py:16-23) -- as one autograd node, so that the gradient of the shared input is
+    formed inside the second backward-data launch (epilogue `+ res_post`) instead of by autograd's separate accumulation add
+    (three passes over a 1/4-resolution tensor).  Same kernels, same values: (a + b) is one fp32 addition either way."""
+
+    @staticmethod
+    def forward(ctx, x, wa, wb, want_stats):
+        x, wa, wb = _req(x, "conv_pair"), _req(wa, "conv_pair.weight_a"), _req(wb, "conv_pair.weight_b")
+        ctx.save_for_backward(x, wa, wb)
+        with torch.cuda.device_of(x):
+            if want_stats:
+                ya, pa = _conv_forward_impl(x, None, wa, 2, False, want_stats=True)
+                yb, pb = _conv_forward_impl(x, None, wb, 1, False, want_stats=True)
+            else:
+                ya, pa = _conv_forward_impl(x, None, wa, 2, False), None
+                yb, pb = _conv_forward_impl(x, None, wb, 1, False), None
+        none = lambda: torch.empty((0,), device=x.device, dtype=torch.float64)
+        pa, pb = (none() if pa is None else pa), (none() if pb is None else pb)
+        ctx.mark_non_differentiable(pa, pb)
+        return ya, pa, yb, pb
+
+    @staticmethod
+    def backward(ctx, dya, _dpa, dyb, _dpb):
+        x, wa, wb = ctx.saved_tensors
+        dya, dyb = _req(dya, "conv_pair.backward"), _req(dyb, "conv_pair.backward")
+        Ca, Cin, Cb = wa.shape[0], wa.shape[1], wb.shape[0]
+        if Cb not in (32, 64):
+            raise RuntimeError("1x1x1 conv backward-data needs 32 or 64 output channels")
+        with torch.cuda.device_of(x):
+            gb = _conv_sliced(dyb, None, wb.reshape(Cb, Cin).contiguous(), Cb, Cin, 1, 1, 0, 1, 1, False)
+            gx = _conv_sliced(dya, None, wa, Ca, Cin, 27, 1, 0, 3, 2, True, res_post=gb)     # d(x) = A^T dya + B^T dyb
+            if gx.shape != x.shape:
+                raise RuntimeError("stride-2 conv backward needs even input dims")
+            gwa, gwb = torch.empty_like(wa), torch.empty_like(wb)
+            _wgrad(x, dya, gwa, 0, Cin, Ca, 3, 2, Cin * 27, 27)
+            _wgrad(x, dyb, gwb, 0, Cin, Cb, 1, 1, Cin, 1)
+        return gx, gwa, gwb, None
+
+
+PAIR_FUSE = os.environ.get("DCA_PAIR_FUSE", "1") != "0"
+
+
+def convbn3d_pair(x, conv_a, bn_a, slope_a, conv_b, bn_b, slope_b):
+    """(act(BN_a(conv_a(x))), act(BN_b(conv_b(x)))) for conv_a = Conv3d(k3, s2, p1), conv_b = Conv3d(k1) over the SAME x;
+    training path: one autograd node for the two convolutions (`_ConvPair`), otherwise two `convbn3d` calls"""
+    inference = (not bn_a.training and not bn_b.training and not torch.is_grad_enabled())
+    ok = (PAIR_FUSE and not inference and _lp_dtype() is None and conv_a.kernel_size[0] == 3 and conv_a.stride[0] == 2
+          and conv_b.kernel_size[0] == 1 and conv_b.weight.shape[0] in (32, 64) and x.dtype == torch.float32
+          and not isinstance(conv_a, torch.nn.ConvTranspose3d) and all(d % 2 == 0 for d in x.shape[2:]))
+    if not ok:
+        return convbn3d(x, conv_a, bn_a, slope_a), convbn3d(x, conv_b, bn_b, slope_b)
+    stats = bool(BN_FUSE and bn_a.training and bn_b.training)
+    ya, pa, yb, pb = _ConvPair.apply(x, conv_a.weight, conv_b.weight, stats)
+    za = bn_act(ya, bn_a, slope_a, stats_part=pa if pa.numel() else None)
+    zb = bn_act(yb, bn_b, slope_b, stats_part=pb if pb.numel() else None)
+    return za, zb
+
+
 def conv3d(x, weight, stride=1, transposed=False, x2=None):
     if (not transposed and x2 is None and weight.shape[0] == 1 and weight.shape[2] == 3 and int(stride) == 1
             and weight.shape[1] in (32, 64)):
