@@ -327,8 +327,9 @@ __global__ __launch_bounds__(256) void avgpool3d_fwd_kernel(const float* __restr
   }
 }
 
-__global__ __launch_bounds__(256) void avgpool3d_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int Di,
-                                                            int Hi, int Wi, int Do, int Ho, int Wo) {
+__global__ __launch_bounds__(256) void avgpool3d_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
+                                                            const float* __restrict__ res, int Di, int Hi, int Wi, int Do,
+                                                            int Ho, int Wo) {
   const long row = blockIdx.x;
   const int d = (int)(row % Di);
   const long nc = row / Di;
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(256) void avgpool3d_bwd_kernel(const float* __restr
           const int ok = (a <= dn) & (b <= hn) & (c <= wn) & (int)(od < Do) & (int)(oh < Ho) & (int)(ow < Wo);
           s += dca_bload1(gr, ((od * Ho + oh) * Wo + ow) * 4, ok);
         }
-    gx[row * HW + i] = s * (1.0f / 27.0f);
+    gx[row * HW + i] = s * (1.0f / 27.0f) + (res ? res[row * HW + i] : 0.f);
   }
 }
 
@@ -413,7 +414,8 @@ __global__ __launch_bounds__(256) void avgpool3d_fwd_tiled_kernel(const float* _
 // Backward with 16-byte stores for aligned outputs (Wi % 4 == 0): a thread produces 4 consecutive fine w of one row
 // from the <= 2 x 2 x 3 coarse gradients above them; per-element summation order as in the scalar kernel.
 __global__ __launch_bounds__(256) void avgpool3d_bwd_vec_kernel(const float* __restrict__ gy, float* __restrict__ gx,
-                                                                int Di, int Hi, int Wi, int Do, int Ho, int Wo) {
+                                                                const float* __restrict__ res, int Di, int Hi, int Wi, int Do,
+                                                                int Ho, int Wo) {
   const long row = blockIdx.x;
   const int d = (int)(row % Di);
   const long nc = row / Di;
@@ -446,6 +448,10 @@ __global__ __launch_bounds__(256) void avgpool3d_bwd_vec_kernel(const float* __r
           s += (e & 1) ? g[a][b][(e + 1) >> 1] : 0.f;
         }
       o[e] = s * (1.0f / 27.0f);
+    }
+    if (res) {   // + another gradient of the same input (ops._PoolFork): saves autograd's separate accumulation pass
+      const float4 r = *(const float4*)(res + (row * Hi + h) * (long)Wi + 4 * t);
+      o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
     }
     *(float4*)(gx + (row * Hi + h) * (long)Wi + 4 * t) = make_float4(o[0], o[1], o[2], o[3]);
   }
@@ -767,17 +773,18 @@ extern "C" int dca_avgpool3d_fwd(const float* x, float* y, long NC, int Di, int 
   return dca_launch_status();
 }
 
-extern "C" int dca_avgpool3d_bwd(const float* gy, float* gx, long NC, int Di, int Hi, int Wi, hipStream_t stream) {
+extern "C" int dca_avgpool3d_bwd(const float* gy, float* gx, const float* res, long NC, int Di, int Hi, int Wi,
+                                 hipStream_t stream) {
   DCA_REQUIRE(gy && gx && NC > 0 && Di > 0 && Hi > 0 && Wi > 0);
   const int Do = (Di + 1) / 2, Ho = (Hi + 1) / 2, Wo = (Wi + 1) / 2;
   DCA_REQUIRE((long)Di * Hi * Wi * 4 < 0x7ffffff0L && NC * Di < 0x7fffffffL);
-  if (Wi % 4 == 0 && (((uintptr_t)gx) & 15) == 0) {
+  if (Wi % 4 == 0 && ((((uintptr_t)gx) | ((uintptr_t)res)) & 15) == 0) {
     hipLaunchKernelGGL(avgpool3d_bwd_vec_kernel, dim3((unsigned)(NC * Di), cdiv((long)Hi * (Wi / 4), 1024)), dim3(256), 0,
-                       stream, gy, gx, Di, Hi, Wi, Do, Ho, Wo);
+                       stream, gy, gx, res, Di, Hi, Wi, Do, Ho, Wo);
     return dca_launch_status();
   }
   hipLaunchKernelGGL(avgpool3d_bwd_kernel, dim3((unsigned)(NC * Di), cdiv((long)Hi * Wi, 1024)), dim3(256), 0, stream, gy,
-                     gx, Di, Hi, Wi, Do, Ho, Wo);
+                     gx, res, Di, Hi, Wi, Do, Ho, Wo);
   return dca_launch_status();
 }
 

@@ -106,7 +106,10 @@ class cva(nn.Module):
                 raise NotImplementedError("reduced-precision path: only the down-sampling form used by GwcNet")
             return self._forward_lp(cost_volume, res_post)
         if downsample:
-            cost_down = self.downsample(cost_volume)
+            # pooled input + the input itself for `fuse` from one autograd node (ops._PoolFork): the two gradients of the
+            # cost volume are summed inside the pooling backward kernel
+            pooled, cost_volume = ops.avg_pool3d_fork(cost_volume)
+            cost_down = self.downsample[1](pooled, slope=0.0)
             prob_volume = self.classify(cost_down).squeeze(1)
             aug_down = self.slc_net(cost_down, prob_volume)
             aug = ops.trilinear_upsample(aug_down, 2)

@@ -1095,8 +1095,44 @@ class _AvgPool3d(torch.autograd.Function):
         N, C, D, H, W = ctx.shape
         gx = torch.empty(ctx.shape, device=gy.device, dtype=torch.float32)
         with torch.cuda.device_of(gy):
-            _chk(_L().dca_avgpool3d_bwd(_ptr(gy), _ptr(gx), N * C, D, H, W, _stream()), "dca_avgpool3d_bwd")
+            _chk(_L().dca_avgpool3d_bwd(_ptr(gy), _ptr(gx), None, N * C, D, H, W, _stream()), "dca_avgpool3d_bwd")
         return gx
+
+
+class _PoolFork(torch.autograd.Function):
+    """(AvgPool3d(3, 2, 1)(x), x) as ONE autograd node: the second output is x itself, for a second consumer (a cva block
+    pools its input AND feeds it to the `fuse` convolution, models/augment/cva.py:62-69).  Backward adds that consumer's
+    gradient inside the pooling backward kernel (`res`) instead of leaving the sum to autograd's accumulation pass."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _req(x, "avg_pool3d")
+        N, C, D, H, W = x.shape
+        y = torch.empty((N, C, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2), device=x.device, dtype=torch.float32)
+        with torch.cuda.device_of(x):
+            _chk(_L().dca_avgpool3d_fwd(_ptr(x), _ptr(y), N * C, D, H, W, _stream()), "dca_avgpool3d_fwd")
+        ctx.shape = tuple(x.shape)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, gy, gx2):
+        if gy is None:
+            return gx2
+        gy = _req(gy, "avg_pool3d.backward")
+        res = _opt(gx2, "avg_pool3d.backward")
+        N, C, D, H, W = ctx.shape
+        gx = torch.empty(ctx.shape, device=gy.device, dtype=torch.float32)
+        with torch.cuda.device_of(gy):
+            _chk(_L().dca_avgpool3d_bwd(_ptr(gy), _ptr(gx), _ptr(res), N * C, D, H, W, _stream()), "dca_avgpool3d_bwd")
+        return gx
+
+
+def avg_pool3d_fork(x):
+    """(avg_pool3d_k3s2p1(x), x') with x' = x for a second consumer whose gradient is added inside the pooling backward
+    kernel (training path; plain pooling and x itself otherwise)"""
+    if PAIR_FUSE and torch.is_grad_enabled() and x.requires_grad and x.dtype == torch.float32:
+        return _PoolFork.apply(x)
+    return avg_pool3d_k3s2p1(x), x
 
 
 class _Trilinear(torch.autograd.Function):
