@@ -57,7 +57,11 @@ class _Classify(nn.Sequential):
         super().__init__(ConvBn3d(c, c, 3, 1, 1), nn.ReLU(inplace=True),
                          nn.Conv3d(c, 1, kernel_size=3, padding=1, stride=1, bias=False))
 
-    def forward(self, x):
+    def forward(self, x, alias=False):
+        """alias=True: returns (logits, x') with x' = x for the other consumers of x (ops._Conv3d.forward, `alias`)"""
+        if alias:
+            h, xa = self[0](x, slope=0.0, alias=True)
+            return conv3d_plain(h, self[2]), xa
         h = self[0](x, slope=0.0)
         if h.dtype != torch.float32:            # reduced-precision inference: 2-byte features, fp32 logits
             return ops.conv3d_c1_lp(h, self[2].weight)

@@ -84,7 +84,10 @@ class _Dres1(nn.Sequential):
         super().__init__(ConvBn3d(32, 32, 3, 1, 1), nn.ReLU(inplace=True), ConvBn3d(32, 32, 3, 1, 1))
 
     def forward(self, x):
-        return self[2](self[0](x, slope=0.0), slope=1.0, res_post=x)
+        # the residual reads x through the first convolution's alias output: its gradient is added inside that convolution's
+        # backward-data launch (ops._Conv3d.forward, `alias`)
+        h, xa = self[0](x, slope=0.0, alias=True)
+        return self[2](h, slope=1.0, res_post=xa)
 
 
 class GwcNet(nn.Module):
@@ -147,18 +150,28 @@ class GwcNet(nn.Module):
                                  out_dtype=torch.float32 if lp is None else lp)
         cost0 = self.dres0(volume)
         cost0 = self.dres1(cost0)                               # dres1(cost0) + cost0
+        heads = self.training and lp is None
+        if heads:
+            # the training heads classif0-2 read cost0 / out1 / out2 FIRST and hand them on as their first convolution's
+            # alias output: the later consumers' gradient is added inside that convolution's backward-data launch instead of
+            # by autograd's accumulation pass (ops._Conv3d.forward, `alias`); same values, other launch order
+            logits0, cost0 = self.classif0(cost0, alias=True)
         prob_volume1, out1 = self.cva1(cost0, res_post=cost0)   # cost0 + augmented_cost
+        if heads:
+            logits1, out1 = self.classif1(out1, alias=True)
         prob_volume2, out2 = self.cva2(out1)
+        if heads:
+            logits2, out2 = self.classif2(out2, alias=True)
         prob_volume3, out3 = self.cva3(out2)
         logits3 = self.classif3(out3).squeeze(1)
         res = {"pred4_q": ops.softargmin(logits3), "prob_volume2": prob_volume2}
         if self.training:
-            res["pred0"] = ops.softmax_dim1(self.classif0(cost0).squeeze(1))
+            res["pred0"] = ops.softmax_dim1(logits0.squeeze(1))
             res["pred_dca1"] = ops.softmax_dim1(ops.trilinear_upsample(prob_volume1, 2).squeeze(1))
             res["pred_dca2"] = ops.softmax_dim1(ops.trilinear_upsample(prob_volume2, 2).squeeze(1))
             res["pred_dca3"] = ops.up_softargmin(prob_volume3.squeeze(1), 8)
-            res["pred1"] = ops.softmax_dim1(self.classif1(out1).squeeze(1))
-            res["pred2"] = ops.softmax_dim1(self.classif2(out2).squeeze(1))
+            res["pred1"] = ops.softmax_dim1(logits1.squeeze(1))
+            res["pred2"] = ops.softmax_dim1(logits2.squeeze(1))
         return res
 
     def forward(self, left, right, disp_true=None):

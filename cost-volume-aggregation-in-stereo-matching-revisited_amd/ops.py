@@ -628,31 +628,37 @@ class _Conv3d(torch.autograd.Function):
     Optional second input x2 = implicit channel concat for the 1x1x1 `fuse` conv."""
 
     @staticmethod
-    def forward(ctx, x, x2, weight, stride, transposed, want_stats=False):
+    def forward(ctx, x, x2, weight, stride, transposed, want_stats=False, alias=False):
         """want_stats: returns (y, part) -- part = the BatchNorm batch-statistics partials of y from the convolution
         kernel's own epilogue (not differentiable; csrc/bn_fused_stats.h), empty where the kernel serving this shape
-        cannot produce them"""
+        cannot produce them.
+        alias (3x3x3 stride 1 only): one more output, x itself, for the OTHER consumers of x -- their summed gradient comes
+        back as that output's gradient and is added inside this convolution's backward-data launch (epilogue `+ res_post`)
+        instead of by autograd's separate accumulation pass."""
         x, weight = _req(x, "conv3d"), _req(weight, "conv3d.weight")
         x2 = _opt(x2, "conv3d.x2")
         ctx.save_for_backward(x, x2, weight)
         ctx.meta = (stride, transposed)
+        ctx.alias = bool(alias)
         ctx.x_amax = None
         with torch.cuda.device_of(x):
             if (CONV_X2 and x2 is None and not transposed and stride == 1 and weight.shape[2] == 3
                     and _x3_eligible(x, None, 3, 1, False, weight.shape[1], weight.shape[0])):
                 ctx.x_amax = _amax_of(x)     # forward and weight gradient scale x by the same word
             if not want_stats:
-                return _conv_forward_impl(x, x2, weight, stride, transposed)
+                y = _conv_forward_impl(x, x2, weight, stride, transposed)
+                return (y, x.view_as(x)) if alias else y
             y, part = _conv_forward_impl(x, x2, weight, stride, transposed, want_stats=True)
         if part is None:
             part = torch.empty((0,), device=x.device, dtype=torch.float64)
         ctx.mark_non_differentiable(part)
-        return y, part
+        return (y, part, x.view_as(x)) if alias else (y, part)
 
     @staticmethod
-    def backward(ctx, dy, _dpart=None):
+    def backward(ctx, dy, *rest):
         x, x2, weight = ctx.saved_tensors
         stride, transposed = ctx.meta
+        g_alias = _opt(rest[-1], "conv3d.backward") if (ctx.alias and rest) else None
         dy = _req(dy, "conv3d.backward")
         ksize = weight.shape[2]
         K = ksize ** 3
@@ -669,8 +675,9 @@ class _Conv3d(torch.autograd.Function):
             elif ksize == 3:
                 Cout, Cin = weight.shape[0], weight.shape[1]
                 if need_x:
-                    if stride == 1:
-                        gx = _conv_sliced(dy, None, weight, Cout, Cin, K, 1, 1, 3, 1, False)   # dy's word: tag or one pass
+                    if stride == 1:   # dy's max-|.| word: tag or one pass; + the other consumers' gradient of x (alias)
+                        gx = _conv_sliced(dy, None, weight, Cout, Cin, K, 1, 1, 3, 1, False, res_post=g_alias)
+                        g_alias = None
                     else:
                         gx = _conv_sliced(dy, None, weight, Cout, Cin, K, 1, 0, 3, 2, True)
                         if gx.shape != x.shape:
@@ -695,7 +702,9 @@ class _Conv3d(torch.autograd.Function):
                     _wgrad(x, dy, gw, 0, C1, Cout, 1, 1, Cin, 1)
                     if x2 is not None:
                         _wgrad(x2, dy, gw, C1, Cin - C1, Cout, 1, 1, Cin, 1)
-        return gx, gx2, gw, None, None, None
+        if g_alias is not None:      # alias on a path without the fused form
+            gx = g_alias if gx is None else gx + g_alias
+        return gx, gx2, gw, None, None, None, None
 
 
 class _ConvPair(torch.autograd.Function):
@@ -1044,7 +1053,7 @@ def _lp_dtype():
     return getattr(_tls, "lp", None)
 
 
-def convbn3d(x, conv, bn, slope=1.0, res_pre=None, res_post=None, x2=None):
+def convbn3d(x, conv, bn, slope=1.0, res_pre=None, res_post=None, x2=None, alias=False):
     """`convbn_3d` (models/submodule.py:121-124) + activation + residual adds, on the HIP kernels.
 
     conv: nn.Conv3d / nn.ConvTranspose3d (bias=False), bn: nn.BatchNorm3d -- used as parameter holders.
@@ -1052,6 +1061,18 @@ def convbn3d(x, conv, bn, slope=1.0, res_pre=None, res_post=None, x2=None):
     batch statistics -> apply, each with a HIP backward."""
     transposed = isinstance(conv, torch.nn.ConvTranspose3d)
     stride = conv.stride[0]
+    if alias:
+        # alias=True: returns (z, x') with x' = x for the other consumers of x (see _Conv3d.forward); plain (z, x) where the
+        # fused form does not apply
+        fuse = (PAIR_FUSE and torch.is_grad_enabled() and x.requires_grad and x2 is None and not transposed and stride == 1
+                and conv.kernel_size[0] == 3 and conv.weight.shape[0] > 1 and _lp_dtype() is None and x.dtype == torch.float32)
+        if not fuse:
+            return convbn3d(x, conv, bn, slope, res_pre, res_post, x2), x
+        stats = bool(BN_FUSE and bn.training)
+        out = _Conv3d.apply(x, None, conv.weight, 1, False, stats, True)
+        y, part, xa = (out[0], out[1], out[2]) if stats else (out[0], None, out[1])
+        z = bn_act(y, bn, slope, res_pre, res_post, part if (part is not None and part.numel()) else None)
+        return z, xa
     if not bn.training and not torch.is_grad_enabled():
         lp = _lp_dtype()
         if lp is not None and not transposed and stride == 1 and conv.kernel_size[0] == 3 and x2 is None:
