@@ -25,9 +25,20 @@ def _newer(path, than):
     return (not os.path.exists(than)) or os.path.getmtime(path) > os.path.getmtime(than)
 
 
+FLAGS_STAMP = os.path.join(OBJ, ".flags")   # the compile flags the objects in OBJ were built with
+
+
+def _flags_changed() -> bool:
+    """objects built with other flags (an ablation / stamp build through DCA_EXTRA_CFLAGS) must not be reused"""
+    try:
+        return open(FLAGS_STAMP).read() != " ".join(FLAGS)
+    except OSError:
+        return True
+
+
 def _stale() -> bool:
     deps = [os.path.join(CSRC, f) for f in sources()] + _headers()
-    return any(_newer(d, LIB) for d in deps if os.path.exists(d))
+    return _flags_changed() or any(_newer(d, LIB) for d in deps if os.path.exists(d))
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -36,6 +47,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     os.makedirs(OBJ, exist_ok=True)
+    force = force or _flags_changed()
     jobs = []
     for src in sources():
         s, o = os.path.join(CSRC, src), os.path.join(OBJ, src[:-4] + ".o")
@@ -51,6 +63,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         list(ex.map(run, jobs))
     objs = [os.path.join(OBJ, s[:-4] + ".o") for s in sources()]
     run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    with open(FLAGS_STAMP, "w") as f:
+        f.write(" ".join(FLAGS))
     return LIB
 
 

@@ -325,15 +325,21 @@ def _amax_word(device):
     return pool[0][i * AMAX_SLOTS:(i + 1) * AMAX_SLOTS]
 
 
+def _ver(t):
+    """version counter of t, or None for an inference tensor (torch.inference_mode(): such a tensor does not track
+    versions -- and cannot be changed in place outside inference mode, so its tag stays valid)"""
+    return None if t.is_inference() else t._version
+
+
 def _tag_amax(t, word):
-    t._dca_amax = (word, t._version)
+    t._dca_amax = (word, _ver(t))
     return t
 
 
 def _amax_of(t):
     """the max-|.| word of tensor t: the producer's if t carries a valid one, else one read pass over t"""
     tag = getattr(t, "_dca_amax", None)
-    if tag is not None and tag[1] == t._version and tag[0].device == t.device:
+    if tag is not None and tag[1] == _ver(t) and tag[0].device == t.device:
         AMAX_STATS["tagged"] += 1
         return tag[0]
     AMAX_STATS["computed"] += 1

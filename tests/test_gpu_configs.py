@@ -124,8 +124,10 @@ def test_train_step_d192_row_crop_all_gradients(variant, capsys):
         print(f"   median {errs[len(errs) // 2]:.3e}   max {errs[-1]:.3e}   tensors {len(errs)}")
     errs = sorted(e for _, e, _ in rows)
     # gates: see test_gpu_parity.py::test_golden_hot_path for why end-to-end train-mode gradients are gated on rel-L2
-    assert errs[len(errs) // 2] <= 5e-3, f"median per-tensor gradient error {errs[len(errs) // 2]:.3e}"
-    bad = [(n, e) for n, e, nr in rows if e > 1.5e-2 and nr > 1e-6]   # measured max 4.8e-3 (G), 6.9e-3 (GC)
+    # gates = ~2x what is measured (round 2: median 9.7e-4 / max 4.1e-3 (G), 1.5e-3 / 3.3e-3 (GC)): a 1 % backward bug in
+    # one branch must not pass
+    assert errs[len(errs) // 2] <= 3e-3, f"median per-tensor gradient error {errs[len(errs) // 2]:.3e}"
+    bad = [(n, e) for n, e, nr in rows if e > 8e-3 and nr > 1e-6]
     assert not bad, bad
 
 
@@ -153,3 +155,21 @@ def test_wgrad_full_size_batch4_is_deterministic_and_additive():
         err = ((g4a - 4 * g1).norm() / (4 * g1).norm()).item()
         assert err <= 2e-5, f"{name}: batch-4 gradient is not 4x the single-sample gradient (rel {err:.2e})"
         del x4, dy4
+
+
+def test_eval_forward_under_inference_mode_equals_no_grad():
+    """the f16x2 operand-maxima tags read `t._version`, which inference tensors do not track -- the eval path must
+    run (and give the same bits) under torch.inference_mode(), hot path alone and the whole GwcNet.forward."""
+    from dcanet_amd.models.gwcnet_dca_g import GwcNet
+    m = load_seeded(GwcNet(32, use_concat_volume=False)).to(DEV).eval()
+    fL, fR = seeded_tensor("imode.fL", (1, 320, 16, 32)).to(DEV), seeded_tensor("imode.fR", (1, 320, 16, 32)).to(DEV)
+    left, right = seeded_tensor("imode.l", (1, 3, 32, 64)).to(DEV), seeded_tensor("imode.r", (1, 3, 32, 64)).to(DEV)
+    with torch.no_grad():
+        a = m.hot_path(fL, fR)["pred4_q"].clone()
+        wa = m(left, right)[0].clone()
+    with torch.inference_mode():
+        b = m.hot_path(fL, fR)["pred4_q"].clone()
+        wb = m(left, right)[0].clone()
+        fi = fL * 1.0                       # an inference tensor as INPUT
+        c = m.hot_path(fi, fR)["pred4_q"].clone()
+    assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(wa, wb)

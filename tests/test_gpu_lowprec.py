@@ -220,10 +220,19 @@ def test_reduced_precision_epe_gate_full_size(capsys):
             print(f"   {name:12s} |dEPE| uniform GT {abs(epe(full, gt) - epe(ref, gt)):.2e}   near GT {abs(epe(full, near) - epe(ref, near)):.2e}"
                   f"   mean|d| {dev.mean().item():.3e}   max|d| {dev.max().item():.3e}")
     assert (f32 - ref).abs().max().item() <= 1e-3
+    # Gates.  The SURVEY gate (|dEPE| <= 1e-3 against the uniform ground truth) is insensitive on its own: EPE_ref is ~48 px
+    # there and sign-symmetric errors cancel.  So the per-pixel deviation from the fp32 oracle is bounded at ~1.5x what is
+    # measured (bf16 mean 0.069 / max 0.67 px, fp16 0.0083 / 0.068 px), and |dEPE| is also gated against a ground truth
+    # CLOSE to the prediction (oracle + N(0,1) px), where fp16 meets 1e-3 and bf16 does not (measured 2.9e-3: 8-bit
+    # mantissas through ~40 layers) -- fp16 is the supported reduced-precision type for the 1e-3 EPE figure
+    # (INTEGRATION.md section 5), bf16 is held to 5e-3 there.
     for name, full in rows[1:]:
+        bf = name == "bfloat16"
         assert abs(epe(full, gt) - epe(ref, gt)) <= 1e-3, name
+        assert abs(epe(full, near) - epe(ref, near)) <= (5e-3 if bf else 1e-3), name
         dev = (full - ref).abs()
-        assert dev.mean().item() <= (0.3 if name == "bfloat16" else 0.05), (name, dev.mean().item())
+        assert dev.mean().item() <= (0.1 if bf else 0.015), (name, dev.mean().item())
+        assert dev.max().item() <= (1.0 if bf else 0.12), (name, dev.max().item())
 
 
 def test_reduced_precision_is_inference_only():
@@ -264,4 +273,4 @@ def test_config5_kitti_frame_fp16_hipgraph(capsys):
     dev = (full - ref).abs()
     with capsys.disabled():
         print(f"\n[config 5, 384x1248 fp16 graph] |dEPE| {abs(epe(full) - epe(ref)):.2e}  mean|d| {dev.mean().item():.3e}  max|d| {dev.max().item():.3e}")
-    assert abs(epe(full) - epe(ref)) <= 1e-3 and dev.mean().item() <= 0.05
+    assert abs(epe(full) - epe(ref)) <= 1e-3 and dev.mean().item() <= 0.015 and dev.max().item() <= 0.15
