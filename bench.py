@@ -102,7 +102,7 @@ def eval_step(m, fL, fR, guid):
 
 
 
-PMC_FILE = "r02_pmc_traffic.json"       # written by tools/pmc_collect.sh + tools/pmc_summarise.py (separate --pmc passes)
+PMC_FILE = "r03_pmc_traffic.json"       # written by tools/pmc_collect.sh + tools/pmc_summarise.py (separate --pmc passes)
 PEAK_BF16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
 PEAK_HBM_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 # algorithmic work of the eval forward at 544x960 / D=192 (G variant), fp32
@@ -137,14 +137,18 @@ def kernel_roofline(device, dtype="f32"):
             ops._chk(lib.dca_conv3d_x3_forward(ops._ptr(x), ops._ptr(wx), ops._ptr(y), None, None, None, None, 1.0, 1,
                                                32, 32, d, h, w, ops._stream()), "x3 forward")
 
-        def run_x2_factory():
+        def run_x2_factory(packed):
+            # the launch alone: in the network the per-channel exponents come with the operand (its producer, a BatchNorm
+            # kernel, emits them) and the weights are packed by a ~3 us kernel per launch (dca_conv3d_x2_prep_weight)
             w2 = torch.empty((lib.dca_conv3d_x2_weight_bytes(32, 32) // 2,), device=device, dtype=torch.int16)
-            ops._chk(lib.dca_conv3d_x2_prep_weight(ops._ptr(wgt), ops._ptr(w2), 32, 32, 0, 0, ops._stream()), "x2 prep")
-            xam = ops._amax_of(x)     # in the network the producer of x (BatchNorm apply) emits this word
+            xin = ops.pack_x2(x) if packed else x
+            xex = ops._exps_of(xin)
+            ops._chk(lib.dca_conv3d_x2_prep_weight(ops._ptr(wgt), ops._ptr(w2), 32, 32, 0, 0, None, 0, ops._ptr(xex),
+                                                   ops._stream()), "x2 prep")
 
             def run_x2():
-                ops._chk(lib.dca_conv3d_x2_forward(ops._ptr(x), ops._ptr(xam), ops._ptr(w2), ops._ptr(y), None, None, None,
-                                                   None, 1.0, None, 1, 32, 32, d, h, w, ops._stream()), "x2 forward")
+                ops._chk(lib.dca_conv3d_x2_forward(ops._ptr(xin), int(packed), ops._ptr(xex), ops._ptr(w2), ops._ptr(y), None,
+                                                   None, None, None, 1.0, None, 1, 32, 32, d, h, w, ops._stream()), "x2 forward")
             return run_x2
 
         cases = []
@@ -159,26 +163,35 @@ def kernel_roofline(device, dtype="f32"):
                           "multiply, fp32 accumulation, fused affine + ReLU epilogue)", "conv3_lp", PEAK_BF16_MFMA_TFLOPS,
                           lambda: ops.conv3d_lp(xl, wgt, lp, sc_, sh_, 0.0)))
         if ops.CONV_X3 and ops.CONV_X2:
-            cases.append(("conv3_f16x2_kernel (3x3x3 32->32 @1/4 res; fp32-grade via power-of-two operand scaling + 2-way f16 "
-                          "split, 3 f16 MFMA products per fp32 product)", "conv3_f16x2", PEAK_BF16_MFMA_TFLOPS / 3.0,
-                          run_x2_factory()))
+            if ops.PACK:
+                cases.append(("conv3_f16x2_kernel<packed operand> (3x3x3 32->32 @1/4 res; fp32-grade via per-channel power-of-two "
+                              "scaling + 2-way f16 split, 3 f16 MFMA products per fp32 product; operand in the packed px2 format "
+                              "its producing BatchNorm kernel wrote: every backward-data launch and the chained forward launches "
+                              "of the training step)", "conv3_f16x2_px2", PEAK_BF16_MFMA_TFLOPS / 3.0, run_x2_factory(True)))
+            cases.append(("conv3_f16x2_kernel (3x3x3 32->32 @1/4 res; same arithmetic, fp32 operand scaled and split while it is "
+                          "staged)", "conv3_f16x2", PEAK_BF16_MFMA_TFLOPS / 3.0, run_x2_factory(False)))
         if ops.CONV_X3:
             cases.append(("conv3_bf16x3_kernel (3x3x3 32->32 @1/4 res; fp32 via exact 3-way bf16 split, 6 bf16 MFMA "
                           "products per fp32 product)", "conv3_bf16x3", PEAK_BF16_MFMA_TFLOPS / 6.0, run_x3))
         cases.append(("conv3_mfma_kernel<S1,Cout32,CK8,tile 4x8x16> (3x3x3 32->32 @1/4 res, fp32 MFMA)", "conv3_mfma",
                       PEAK_FP32_MFMA_TFLOPS, lambda: ops.conv3d_prepared(x, wt, 32, cpad, 32, 3, 1, False)))
-        def run_wgrad(x3, x2=False):
+        def run_wgrad(x3, x2=False, packed=False):
+            xa = ops.pack_x2(x) if packed else x
+
             def f():
                 keep = ops.CONV_X3, ops.CONV_X2
                 ops.CONV_X3, ops.CONV_X2 = x3, x2
                 try:
-                    ops._wgrad(x, x, wgt.new_empty(wgt.shape), 0, 32, 32, 3, 1, 32 * 27, 27)
+                    ops._wgrad(xa, xa, wgt.new_empty(wgt.shape), 0, 32, 32, 3, 1, 32 * 27, 27)
                 finally:
                     ops.CONV_X3, ops.CONV_X2 = keep
             return f
 
         if ops.CONV_X3 and ops.CONV_X2:
-            cases.append(("wgrad3_f16x2_kernel (+reduce) (dW of 3x3x3 32->32 @1/4 res; same 3-product f16 split)",
+            if ops.PACK:
+                cases.append(("wgrad3_f16x2_kernel<packed x, packed dy> (+reduce) (dW of 3x3x3 32->32 @1/4 res; both operands in "
+                              "the packed px2 format)", "wgrad3_f16x2_px2", PEAK_BF16_MFMA_TFLOPS / 3.0, run_wgrad(True, True, True)))
+            cases.append(("wgrad3_f16x2_kernel (+reduce) (dW of 3x3x3 32->32 @1/4 res; same 3-product f16 split, fp32 operands)",
                           "wgrad3_f16x2", PEAK_BF16_MFMA_TFLOPS / 3.0, run_wgrad(True, True)))
         if ops.CONV_X3:
             cases.append(("wgrad3_bf16x3_kernel (+reduce) (dW of 3x3x3 32->32 @1/4 res; same 6-product bf16 split)",
@@ -242,7 +255,7 @@ def kernel_roofline(device, dtype="f32"):
                 out[name]["algorithmic_bytes"] = lp_bytes
                 out[name]["hbm_view"] = {"achieved": round(lp_bytes / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
                                          "unit": "GB/s", "frac": round(lp_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
-            if key in ("conv3_f16x2", "wgrad3_f16x2", "wgrad3s2_f16x2"):
+            if key in ("conv3_f16x2", "wgrad3_f16x2", "wgrad3s2_f16x2", "conv3_f16x2_px2", "wgrad3_f16x2_px2"):
                 out[name]["peak_note"] = "dense f16 MFMA peak (2500) / 3 products per fp32 product"
                 out[name]["executed_f16"] = {"achieved": round(3 * tf, 1), "peak": PEAK_BF16_MFMA_TFLOPS,
                                              "unit": "TFLOP/s", "frac": round(3 * tf / PEAK_BF16_MFMA_TFLOPS, 4)}
@@ -475,12 +488,14 @@ def main():
             "f16x2_operand_maxima_per_step": {k: (_ops_c.AMAX_STATS[k] - amax0[k]) / args.steps for k in amax0},
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "dtype_note": ("fp32 tensors and fp32 accumulation everywhere; the 3x3x3 stride-1 convolutions and their weight "
-                           "gradients scale each fp32 operand by a power of two taken from its tensor's max |.| and split it "
-                           "into two f16 terms (three f16 MFMA products, operand error <= 2^-22; DCA_CONV=x3: three bf16 "
-                           "terms, six products), the transposed and 1x1x1 convolutions use the three-term bf16 split: "
-                           "measured against fp64 as accurate as the fp32 MFMA kernels "
-                           "(tests/test_gpu_parity.py::test_conv3d_bf16x3_is_fp32_grade); DCA_CONV=fp32 selects the fp32 MFMA "
-                           "kernels") if args.dtype == "f32" and _conv_x3() else
+                           "gradients scale every CHANNEL of an fp32 operand by its own power of two and split it into two f16 "
+                           "terms (three f16 MFMA products, operand error <= 2^-22 per channel; DCA_CONV=x3: three bf16 terms, "
+                           "six products); where a BatchNorm output or gradient has such a convolution as its only reader the "
+                           "BatchNorm kernel writes those two f16 terms (4 bytes per element, like fp32) instead of the fp32 value "
+                           "(packed px2 operand, DCA_PACK=0 switches it off); the transposed and 1x1x1 convolutions use the "
+                           "three-term bf16 split: measured against fp64 as accurate as the fp32 MFMA kernels per output channel "
+                           "(tests/test_gpu_parity.py::test_conv3d_bf16x3_is_fp32_grade, test_f16x2_per_channel_scales); "
+                           "DCA_CONV=fp32 selects the fp32 MFMA kernels") if args.dtype == "f32" and _conv_x3() else
                           ("fp32 MFMA kernels everywhere (DCA_CONV=fp32)" if args.dtype == "f32" else
                            "reduced-precision inference path (NOT the headline): 1/4-res activations stored as " + args.dtype +
                            ", one native MFMA product per multiply with fp32 accumulation in the 3x3x3 stride-1 and 1x1x1 "

@@ -1,9 +1,15 @@
 // 3x3x3 stride-1 convolution on the f16 matrix pipe with fp32-grade accuracy ("f16x2" split emulation).
 //
-// Every fp32 operand is first scaled by a power of two taken from its tensor's max |.| (exact; the scaled maximum lies in
-// [2^14, 2^15), inside the f16 range whatever the magnitude of the tensor -- loss gradients of 1e-9 included) and then split
-// into two f16 terms, x 2^e = h + l with h = f16(x 2^e), l = f16(x 2^e - h): 11 + 11 significand bits plus the sign of l,
-// |x 2^e - h - l| <= 2^-22 |x 2^e| (an fp32 operand itself carries a 2^-24 rounding).  A product w*x is evaluated as the
+// Every fp32 operand is first scaled by a power of two (exact) and then split into two f16 terms, x 2^e = h + l with
+// h = f16(x 2^e), l = f16(x 2^e - h): 11 + 11 significand bits plus the sign of l, |x 2^e - h - l| <= 2^-22 |x 2^e| (an fp32
+// operand itself carries a 2^-24 rounding).  The scales are PER CHANNEL (round 3): input channel k of x is scaled by
+// 2^xexps[k], taken from that channel's max |.| (scaled maximum in [2^14, 2^15): inside the f16 range whatever the magnitude
+// -- loss gradients of 1e-20 included -- and whatever the OTHER channels' magnitudes), and the weight row of output channel
+// o is packed as w[o][k] 2^(f_o - xexps[k]) with f_o chosen so that the row's largest scaled entry lies in [2^14, 2^15)
+// (dca_conv3d_x2_prep_weight, per launch: it needs the operand's exponents).  The accumulator of output channel o is
+// scaled back by 2^-f_o (v_ldexp_f32).  So every output channel is computed to 2^-22 of ITS largest term, like an fp32
+// convolution -- the per-tensor scale of round 2 lost the low term of channels 2^-18 below the tensor's maximum
+// (tests/test_gpu_parity.py::test_f16x2_per_channel_scales).  A product w*x is evaluated as the
 // three partial products of weight >= 2^-11,
 //     w_h x_h + (w_h x_l + w_l x_h)
 // each exact in the MFMA's fp32 accumulator; the dropped w_l x_l is <= 2^-22 relative.  Three v_mfma_f32_32x32x16_f16
@@ -12,11 +18,11 @@
 // fp64 convolutions the kernel measures the same error as the fp32 MFMA kernel (the fp32 accumulation of 27*Cin products
 // dominates both), tests/test_gpu_parity.py.
 //
-// The operand maxima arrive as DCA_AMAX_SLOTS device words per tensor (dca_common.h: one slot per producing workgroup /
-// wave, each the bit pattern of a partial max |x| as an fp32 number; the consumer takes the maximum over the slots): the
-// kernels that produce the operands fill them (bn_apply / bn_bwd_apply, pointwise.hip; this kernel's own epilogue) or
-// dca_amax_f32 computes them; the weight's power of two is chosen by the weight packing kernel and stored behind the
-// packed image.  Nothing is read back by the host; no atomics.
+// The operand arrives either as fp32 (scaled and split while it is staged into LDS) or in the packed px2 format
+// (dca_common.h: already scaled, split and laid out [voxel][8 channels] by the BatchNorm kernel that wrote it -- staging is a
+// copy of 16-byte words, a halo row one contiguous run).  Per-channel maxima travel as slots (dca_common.h) filled by the
+// producers (bn_apply / bn_bwd_apply, pointwise.hip; this kernel's own epilogue) or by dca_cmax_f32.  Nothing is read back
+// by the host; no atomics.
 //
 // Reference operators served: nn.Conv3d(k=3, s=1, p=1) of convbn_3d (models/submodule.py:121-124) in dres0/dres1,
 // Multi_Aggregation and the cva blocks (models/augment/cva.py:13-55), and their backward-data.
@@ -70,6 +76,11 @@ constexpr int B_TERM = 2 * NVOX * 16;              // bytes of one f16 term imag
 constexpr int B_BYTES = NT * B_TERM;               // 69120
 constexpr int A_SLAB = 9 * NT * 1024;              // 9 taps x 2 terms x (64 lanes x 16 B)
 constexpr int LDS_BYTES = B_BYTES + 2 * A_SLAB;    // 105984 of the CU's 163840
+constexpr int MAX_CIN = 256;                       // the per-channel exponent table below
+constexpr int TAB_BYTES = (MAX_CIN + 32 + 8 * 32) * 4;   // xexps[MAX_CIN] | f_o[32] | per-wave channel maxima [8][32]
+constexpr int NP_ITEMS = NT * 2 * NVOX;            // packed-input staging: 4320 16-byte words per chunk = the LDS image itself
+constexpr int KP = (NP_ITEMS + 511) / 512;         // 9 per thread
+constexpr int KP0 = 5;                             // words 0-4 are requested behind the kd 0 phase, 5-8 behind kd 1
 constexpr int NB_ITEMS = 2 * NVOX;                 // (k half, voxel) staging items of 8 channels (unaligned path)
 constexpr int KB = (NB_ITEMS + 511) / 512;         // 5
 constexpr int NROWS = 2 * ID * IH;                 // 120 (k half, d, h) halo rows: 4 aligned quads + 2 edge voxels each
@@ -91,16 +102,16 @@ struct X2Args {
   int D, H, W;
   int nTD, nTH, nTW;
   double* stat_part;         // STATS: one partial {K, n, s, q} per (channel, workgroup): bn_fused_stats.h
-  const unsigned* x_amax;    // max |x|: DCA_AMAX_SLOTS device words (dca_common.h)
-  const float* wtail;        // {2^ew, 2^-ew} behind the packed weight image
-  unsigned* y_amax;          // optional: receives max |y| (DCA_AMAX_SLOTS zero-initialised device words)
+  const int* xexps;          // fp32 x: the scale exponent of every input channel (Cin ints); unused for packed x
+  const int* ofo;            // behind the packed weight image: f_o of every output channel (dca_conv3d_x2_prep_weight)
+  unsigned* y_cmax;          // optional (EPI 1): per-channel slots [c][blockIdx.x] that receive max |y| (dca_common.h)
 };
 
 constexpr int STAT_LDS = 8 * FS_WAVE_FLOATS * 4;
 
-// x 2^e = h + l (+ <= 2^-22 relative); `s` = 2^e
-__device__ __forceinline__ void split2(float v, float s, _Float16& h, _Float16& l) {
-  const float u = v * s;          // exact: power of two, scaled maximum < 2^15
+// x 2^e = h + l (+ <= 2^-22 relative)
+__device__ __forceinline__ void split2(float v, int e, _Float16& h, _Float16& l) {
+  const float u = ldexpf(v, e);   // exact (v_ldexp_f32); scaled maximum < 2^15
   h = (_Float16)u;
   l = (_Float16)(u - (float)h);   // the residual is exact in fp32
 }
@@ -110,14 +121,19 @@ __device__ __forceinline__ void split2(float v, float s, _Float16& h, _Float16& 
 // the partial statistics {K, n, sum (y - K), sum (y - K)^2} that dca_bn_finalize_centered consumes (bn_fused_stats.h), so the
 // 200 MB statistics pass over y disappears.  Per tile: 3 vector instructions per output value, a DPP reduction over the 32
 // positions of a wave half, one ds_add_f32 per (half, channel) into a wave-private LDS slot.
-// EPI = false: no affine / residual / activation epilogue (the training-mode launches: forward with BatchNorm statistics,
-// backward-data) -- the epilogue's arrays, descriptors and branches are compiled out
-template <bool VEC, bool STATS, bool EPI>
+// EPI = 0: no epilogue (the training-mode launches: forward with BatchNorm statistics, backward-data) -- the epilogue's
+// arrays, descriptors and branches are compiled out; 1: y = act(v scale + shift + res_pre) + res_post (inference); 2: y = v +
+// res_post only (backward-data that also sums the other consumers' gradient: ops._Conv3d alias, _ConvPair)
+// PIN: x is in the packed px2 format (dca_common.h) -- staging copies 16-byte words
+template <bool VEC, bool STATS, int EPI, bool PIN>
 __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* b_lds = smem;
   char* a_lds = smem + B_BYTES;
-  float* stat_lds = (float*)(smem + LDS_BYTES);     // STATS only (the launch adds STAT_LDS bytes)
+  int* xe_lds = (int*)(smem + LDS_BYTES);           // scale exponents of the input channels (fp32 x)
+  int* fo_lds = xe_lds + MAX_CIN;                   // f_o of this block's 32 output channels
+  float* ycm_lds = (float*)(fo_lds + 32);           // [wave][channel] maxima (y_cmax)
+  float* stat_lds = (float*)(smem + LDS_BYTES + TAB_BYTES);     // STATS only (the launch adds STAT_LDS bytes)
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, half = lane >> 5;
   const int cblk = blockIdx.y;
@@ -138,13 +154,27 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) st_s[r] = st_q[r] = 0.f;
   }
-  float y_am = 0.f;          // max |y| this lane has written (y_amax)
+  float ycm[EPI == 1 ? 16 : 1];          // max |y| this lane has written, per accumulator register = output channel (y_cmax)
+#pragma unroll
+  for (int r = 0; r < (EPI == 1 ? 16 : 1); ++r) ycm[r] = 0.f;
   if constexpr (STATS) {
     for (int i = tid; i < 8 * FS_WAVE_FLOATS; i += 512) stat_lds[i] = 0.f;
-    __syncthreads();
   }
+  // the exponent tables were written by the kernels right in front of this one (dca_conv3d_x2_prep_weight / the producer
+  // of x): device-coherent vector loads, never s_load (dca_common.h)
+  if constexpr (!PIN) {
+    for (int i = tid; i < a.NCH * 16; i += 512) xe_lds[i] = i < a.Cin ? dca_coherent_loadi(a.xexps + i) : 0;
+  }
+  if (tid < 32) fo_lds[tid] = dca_coherent_loadi(a.ofo + cblk * 32 + tid);
+  __syncthreads();
   if (t_begin >= t_end) {
-    if constexpr (STATS) fs_flush(stat_lds, 8, tid, cblk * 32, a.Cout, a.stat_part, gridDim.x, blockIdx.x);
+    if constexpr (STATS) {
+      __syncthreads();
+      fs_flush(stat_lds, 8, tid, cblk * 32, a.Cout, a.stat_part, gridDim.x, blockIdx.x);
+    }
+    if constexpr (EPI == 1) {   // a workgroup without tiles still owns its slot of the per-channel maxima
+      if (a.y_cmax && tid < 32 && cblk * 32 + tid < a.Cout) a.y_cmax[(long)(cblk * 32 + tid) * DCA_AMAX_CSLOTS + blockIdx.x] = 0u;
+    }
     return;
   }
 
@@ -167,9 +197,6 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
   const int P = a.NCH * 3;   // phases: (chunk, kd)
   const long wbytes = (long)P * A_SLAB;
   const __amdgpu_buffer_rsrc_t wr = dca_rsrc((const char*)a.wx + (long)cblk * wbytes, wbytes);
-  const int xexp = x2_scale_exp(dca_amax_get(a.x_amax));
-  const float xs = x2_pow2(xexp);                        // operand scale
-  const float inv = x2_pow2(-xexp) * dca_coherent_loadf(a.wtail + 1);   // accumulator -> fp32 result
 
 #if X2_STAMP
   unsigned long long* stamps = (unsigned long long*)a.res_post;
@@ -177,7 +204,8 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
   const bool stamp_on = blockIdx.x == 0 && blockIdx.y == 0 && wv == 0;
   int stamp_k = 0;
 #endif
-  const bool has_aff = EPI && a.scale != nullptr, has_pre = EPI && a.res_pre != nullptr, has_post = EPI && a.res_post != nullptr;
+  const bool has_aff = EPI == 1 && a.scale != nullptr, has_pre = EPI == 1 && a.res_pre != nullptr;
+  const bool has_post = EPI == 2 || (EPI == 1 && a.res_post != nullptr);
   float4 ra[KA];
   auto load_A = [&](int p) __attribute__((always_inline)) {
 #pragma unroll
@@ -198,11 +226,20 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
   //  VEC (W % 4 == 0, 16-byte aligned x): a thread owns one aligned quad of 4 voxels along W (8 x b128, one per
   //  channel of its k half) and, for tid < 240, one of the two edge voxels of a row (8 x b32): 16 loads per thread.
   //  Otherwise: 5 single-voxel items of 8 x b32.
-  float4 rq[VEC ? 8 : 1];
-  float re[VEC ? 8 : 1];
-  float rb[VEC ? 1 : KB][8];
-  int item_crd[VEC ? 2 : KB];  // packed halo coordinates of the thread's items, fixed for the whole kernel
-  if constexpr (VEC) {
+  //  PIN (packed x): 9 16-byte words per thread, word i of the chunk's [term][k half][voxel] image = LDS byte 16 i.
+  float4 rq[(VEC && !PIN) ? 8 : 1];
+  float re[(VEC && !PIN) ? 8 : 1];
+  float rb[(VEC || PIN) ? 1 : KB][8];
+  float4 rp[PIN ? KP : 1];
+  int item_crd[PIN ? KP : (VEC ? 2 : KB)];  // packed halo coordinates of the thread's items, fixed for the whole kernel
+  if constexpr (PIN) {
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+      const int it = tid + 512 * k, term = it / (2 * NVOX), rem = it - term * (2 * NVOX), kh = rem / NVOX, v = rem - kh * NVOX;
+      const int id = v / (IH * IW), r2 = v - id * (IH * IW), ih = r2 / IW, iw = r2 - ih * IW;
+      item_crd[k] = (it < NP_ITEMS) ? (id | (ih << 8) | (iw << 16) | (kh << 24) | (term << 25)) : -1;
+    }
+  } else if constexpr (VEC) {
     {
       const int row = tid >> 2, q = tid & 3, kh = row / (ID * IH), rem = row - kh * (ID * IH), id = rem / IH, ih = rem - id * IH;
       item_crd[0] = (tid < NQUAD) ? (id | (ih << 8) | ((1 + 4 * q) << 16) | (kh << 24)) : -1;
@@ -235,7 +272,20 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
   // part 0 = items 0-2, part 1 = items 3-4; part -1: everything
   auto load_B = [&](int part, int n, int d0, int h0, int w0, int chunk) __attribute__((always_inline)) {
     const __amdgpu_buffer_rsrc_t xr = dca_rsrc(a.x + (long)n * sample, sample * 4);
-    if constexpr (VEC) {
+    if constexpr (PIN) {
+      // [term][channel group][voxel][8 f16]: the word of (term, group g, voxel v) sits at term * (Cin * S * 2) + (g * S + v) * 16
+      const int tbytes = a.Cin * cstride * 2, ngrp = a.Cin >> 3;
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        if ((part == 0 && k >= KP0) || (part == 1 && k < KP0)) continue;
+        const int crd = item_crd[k];
+        const int di = d0 - 1 + (crd & 255), hi = h0 - 1 + ((crd >> 8) & 255), wi = w0 - 1 + ((crd >> 16) & 255);
+        const int g = chunk * 2 + ((crd >> 24) & 1);
+        const int ok = (int)(crd >= 0) & (int)((unsigned)di < (unsigned)a.D) & (int)((unsigned)hi < (unsigned)a.H) &
+                       (int)((unsigned)wi < (unsigned)a.W) & (int)(g < ngrp);
+        rp[k] = dca_bload4(xr, ((crd >> 25) & 1) * tbytes + (g * cstride + (di * a.H + hi) * a.W + wi) * 16, ok);
+      }
+    } else if constexpr (VEC) {
       int c0, okq, c0e, oke;
       const int offq = item_off(item_crd[0], d0, h0, w0, chunk, c0, okq);  // a quad is inside W or outside as a whole
       const int offe = item_off(item_crd[1], d0, h0, w0, chunk, c0e, oke);
@@ -256,12 +306,14 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
       }
     }
   };
-  auto split_store = [&](const float (&v)[8], int vox_off) __attribute__((always_inline)) {
+  auto split_store = [&](const float (&v)[8], const int* ex, int vox_off) __attribute__((always_inline)) {
+    const int4 e0 = *(const int4*)ex, e1 = *(const int4*)(ex + 4);     // the 8 channels' exponents (LDS table)
+    const int e[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
     f16x8 hv, lv;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       _Float16 h, l;
-      split2(v[j], xs, h, l);
+      split2(v[j], e[j], h, l);
       hv[j] = h; lv[j] = l;
     }
     *(f16x8*)(b_lds + vox_off) = hv;
@@ -270,24 +322,30 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
   auto crd_lds = [&](int crd) __attribute__((always_inline)) {  // byte offset of the item's (first) voxel in a term image
     return ((((crd >> 24) & 1) * ID + (crd & 255)) * IH + ((crd >> 8) & 255)) * IW * 16 + ((crd >> 16) & 255) * 16;
   };
-  auto store_B = [&]() __attribute__((always_inline)) {
-    if constexpr (VEC) {
+  // chunk = the channel chunk the staged registers belong to (its exponents)
+  auto store_B = [&](int chunk) __attribute__((always_inline)) {
+    if constexpr (PIN) {
+#pragma unroll
+      for (int k = 0; k < KP; ++k)
+        if (item_crd[k] >= 0) *(float4*)(b_lds + (tid + 512 * k) * 16) = rp[k];
+    } else if constexpr (VEC) {
       if (item_crd[0] >= 0) {
+        const int* ex = xe_lds + chunk * 16 + ((item_crd[0] >> 24) & 1) * 8;
         const int o = crd_lds(item_crd[0]);
         const float v0[8] = {rq[0].x, rq[1].x, rq[2].x, rq[3].x, rq[4].x, rq[5].x, rq[6].x, rq[7].x};
         const float v1[8] = {rq[0].y, rq[1].y, rq[2].y, rq[3].y, rq[4].y, rq[5].y, rq[6].y, rq[7].y};
         const float v2[8] = {rq[0].z, rq[1].z, rq[2].z, rq[3].z, rq[4].z, rq[5].z, rq[6].z, rq[7].z};
         const float v3[8] = {rq[0].w, rq[1].w, rq[2].w, rq[3].w, rq[4].w, rq[5].w, rq[6].w, rq[7].w};
-        split_store(v0, o); split_store(v1, o + 16); split_store(v2, o + 32); split_store(v3, o + 48);
+        split_store(v0, ex, o); split_store(v1, ex, o + 16); split_store(v2, ex, o + 32); split_store(v3, ex, o + 48);
       }
       if (item_crd[1] >= 0) {
         const float v[8] = {re[0], re[1], re[2], re[3], re[4], re[5], re[6], re[7]};
-        split_store(v, crd_lds(item_crd[1]));
+        split_store(v, xe_lds + chunk * 16 + ((item_crd[1] >> 24) & 1) * 8, crd_lds(item_crd[1]));
       }
     } else {
 #pragma unroll
       for (int k = 0; k < KB; ++k)
-        if (item_crd[k] >= 0) split_store(rb[k], crd_lds(item_crd[k]));
+        if (item_crd[k] >= 0) split_store(rb[k], xe_lds + chunk * 16 + ((item_crd[k] >> 24) & 1) * 8, crd_lds(item_crd[k]));
     }
   };
   auto decode = [&](int tile, int& n, int& d0, int& h0, int& w0) __attribute__((always_inline)) {
@@ -302,7 +360,7 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
   decode(t_begin, n, d0, h0, w0);
   load_B(-1, n, d0, h0, w0, 0);
   load_A(0);
-  store_B();
+  store_B(0);
   store_A(0);
   load_A(1);   // P >= 3
   __syncthreads();
@@ -351,7 +409,7 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
       // use and waits on it.
       auto phase = [&](auto PART) __attribute__((always_inline)) {
         constexpr int LD = decltype(PART)::value;        // -1: no loads, 0 / 1: staging part
-        constexpr int NLD = LD < 0 ? 0 : (VEC ? 1 : (LD == 0 ? 3 : 2));  // global loads per tap (8 taps)
+        constexpr int NLD = LD < 0 ? 0 : ((VEC || PIN) ? 1 : (LD == 0 ? 3 : 2));  // global loads per tap (8 taps)
         if constexpr (LD >= 0) {
           const bool nt = next_tile;
           load_B(LD, nt ? nn : n, nt ? nd0 : d0, nt ? nh0 : h0, nt ? nw0 : w0, nt ? 0 : chunk + 1);
@@ -401,7 +459,7 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
       if (stage && kd == 2) {
         __syncthreads();  // every wave is done reading the halo tile of this chunk
         X2_MARK(3);
-        store_B();
+        store_B(next_tile ? 0 : chunk + 1);
         X2_MARK(4);
       }
       __syncthreads();
@@ -420,14 +478,20 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
     const __amdgpu_buffer_rsrc_t yr = dca_rsrc(a.y + (long)n * osample, osample * 4);
     const __amdgpu_buffer_rsrc_t pr = dca_rsrc((has_pre ? a.res_pre : a.y) + (long)n * osample, osample * 4);
     const __amdgpu_buffer_rsrc_t qr = dca_rsrc((has_post ? a.res_post : a.y) + (long)n * osample, osample * 4);
-    float sc[EPI ? 16 : 1], sh[EPI ? 16 : 1];  // (re)loaded per tile: holding them across the MFMA phases costs 32 registers
-    if constexpr (EPI) {
+    float sc[EPI == 1 ? 16 : 1], sh[EPI == 1 ? 16 : 1];  // (re)loaded per tile: holding them across the MFMA phases costs 32 registers
+    if constexpr (EPI == 1) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = min(cblk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, a.Cout - 1);
-        sc[r] = (has_aff ? a.scale[co] : 1.f) * inv;
+        sc[r] = has_aff ? a.scale[co] : 1.f;
         sh[r] = has_aff ? a.shift[co] : 0.f;
       }
+    }
+    int nfo[16];   // -f_o of the lane's 16 output channels: the accumulator is scaled back with v_ldexp_f32 (exact)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int4 f4 = *(const int4*)(fo_lds + 8 * q + 4 * half);
+      nfo[4 * q] = -f4.x; nfo[4 * q + 1] = -f4.y; nfo[4 * q + 2] = -f4.z; nfo[4 * q + 3] = -f4.w;
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -453,14 +517,14 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int cu = (r & 3) + 8 * (r >> 2);
-        float v;
-        if constexpr (EPI) {
-          v = acc[t][r] * sc[r] + sh[r];
+        float v = ldexpf(acc[t][r], nfo[r]);
+        if constexpr (EPI == 1) {
+          v = v * sc[r] + sh[r];
           if (has_pre) v += rp[r];
           v = act_apply(v, a.slope);
           if (has_post) v += rq[r];
-        } else {
-          v = acc[t][r] * inv;
+        } else if constexpr (EPI == 2) {
+          v += rq[r];
         }
         if constexpr (STATS) {
           if (stat_first && t == 0) {   // the wave's first tile: the shift of (half, r) = what lane 0 of the half produced
@@ -472,7 +536,7 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
           st_q[r] = fmaf(dlt, dlt, st_q[r]);
         }
         const int okc = ok & (int)(cblk * 32 + cu + 4 * half < a.Cout);
-        y_am = fmaxf(y_am, okc ? fabsf(v) : 0.f);
+        if constexpr (EPI == 1) ycm[r] = fmaxf(ycm[r], okc ? fabsf(v) : 0.f);
 #if X2_NT
         dca_bstore1_nt(yr, v, voff + cu * cstride * 4, okc);
 #else
@@ -501,110 +565,124 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
     __syncthreads();
     fs_flush(stat_lds, 8, tid, cblk * 32, a.Cout, a.stat_part, gridDim.x, blockIdx.x);
   }
-  if (a.y_amax) {   // the consumer's operand maximum, for the next f16x2 convolution: one slot per wave
-    y_am = wave_max(y_am);
-    if (lane == 0) dca_amax_put(a.y_amax, y_am, (blockIdx.y * gridDim.x + blockIdx.x) * 8 + wv);
+  if constexpr (EPI == 1) {
+    if (a.y_cmax) {   // the consumer's per-channel operand maxima, for the next f16x2 convolution: slot [channel][workgroup]
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float m = ycm[r];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));     // over the 32 lanes of the wave half
+        if (l31 == 0) ycm_lds[wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = m;
+      }
+      __syncthreads();
+      if (tid < 32 && cblk * 32 + tid < a.Cout) {
+        float m = ycm_lds[tid];
+        for (int w = 1; w < 8; ++w) m = fmaxf(m, ycm_lds[w * 32 + tid]);
+        a.y_cmax[(long)(cblk * 32 + tid) * DCA_AMAX_CSLOTS + blockIdx.x] = __float_as_uint(m);
+      }
+    }
   }
 }
 
-// Weight packing.  Stage 1 (one workgroup): max |w| of the tensor -> {2^ew, 2^-ew} behind the packed image (ew brings the
-// maximum into [2^14, 2^15)).  Stage 2: wx[cblk][chunk][tap][term][lane][j] (f16): lane (r = lane & 31, h = lane >> 5)
-// holds A[row = output channel cblk*32 + r][k = input channel chunk*16 + 8h + j] of the tap, scaled by 2^ew and split into
-// term 0/1 = h/l; zero padded.  Source indexing as dca_conv3d_prep_weight: src_ab ? src[a][b][27] : src[b][a][27]; flip
-// reverses the tap order.
-__global__ __launch_bounds__(1024) void x2_weight_scale_kernel(const float* __restrict__ src, long count,
-                                                               float* __restrict__ tail) {
-  float m = 0.f;
-  for (long i = threadIdx.x; i < count; i += 1024) m = fmaxf(m, fabsf(src[i]));
-  m = wave_max(m);
-  __shared__ float red[16];
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+// Weight packing, once per launch (it needs the exponents of the operand the convolution is about to read).  One workgroup
+// per block of 32 output channels:
+//   1. xexps[k]: given, or (slots != null) derived here from the operand's per-channel maxima and written out for the
+//      weight-gradient kernel that reads the same operand later;
+//   2. f_o = 14 - max over (k, tap) of (exponent of w[o][k][tap]) - xexps[k]: the row's largest scaled entry in [2^14, 2^15);
+//   3. wx[cblk][chunk][tap][term][lane][j] (f16): lane (r = lane & 31, h = lane >> 5) holds A[row = output channel
+//      cblk*32 + r][k = input channel chunk*16 + 8h + j] of the tap = w 2^(f_o - xexps[k]), split into term 0/1 = h/l;
+//      zero padded;  f_o goes behind the images (ofo[cblk*32 + r]).
+// Source indexing as dca_conv3d_prep_weight: src_ab ? src[a][b][27] : src[b][a][27]; flip reverses the tap order.
+__global__ __launch_bounds__(1024) void x2_prep_weight_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
+                                                               int A, int Bn, int NCH, int src_ab, int flip,
+                                                               const unsigned* __restrict__ slots, int nslots,
+                                                               int* __restrict__ xexps, int xexps_given, int* __restrict__ ofo) {
+  __shared__ int xe[MAX_CIN];
+  __shared__ int rowmax[32];
+  const int tid = threadIdx.x, cblk = blockIdx.x;
+  if (slots && !xexps_given) {     // 16 threads per channel, 64 channels per round
+    for (int c0 = 0; c0 < A; c0 += 64) {
+      const int c = c0 + (tid >> 4), l = tid & 15;
+      unsigned v = 0;
+      if (c < A)
+        for (int i = l; i < nslots; i += 16) { const unsigned u = slots[(long)c * DCA_AMAX_CSLOTS + i]; v = v > u ? v : u; }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { const unsigned u = (unsigned)__shfl_xor((int)v, o, 64); v = v > u ? v : u; }
+      if (c < A && l == 0) {
+        const int e = x2_scale_exp(v);
+        xe[c] = e;
+        if (cblk == 0) xexps[c] = e;
+      }
+    }
+  } else {
+    for (int c = tid; c < A; c += 1024) xe[c] = dca_coherent_loadi(xexps + c);
+  }
+  if (tid < 32) rowmax[tid] = -100000;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
-    const int ew = x2_scale_exp(__float_as_uint(m));
-    tail[0] = x2_pow2(ew);
-    tail[1] = x2_pow2(-ew);
-    tail[2] = m;
-    tail[3] = 0.f;
+  // row r = tid >> 5 (32 threads per output channel): exponent of the largest |w 2^-xexps[k]| of the row
+  {
+    const int r = tid >> 5, l = tid & 31, bi = cblk * 32 + r;
+    int m = -100000;
+    if (bi < Bn) {
+      for (int i = l; i < A * 27; i += 32) {
+        const int ai = i / 27, tap = i - ai * 27;
+        const float v = src_ab ? src[((long)ai * Bn + bi) * 27 + tap] : src[((long)bi * A + ai) * 27 + tap];
+        const int be = (int)((__float_as_uint(v) >> 23) & 255);      // biased exponent; 0: zero / denormal -> ignored
+        const int e = be == 0 ? -100000 : be - 127 - xe[ai];
+        m = m > e ? m : e;
+      }
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { const int u = __shfl_xor(m, o, 64); m = m > u ? m : u; }
+    if (l == 0) {
+      const int fo = m <= -100000 ? 0 : 14 - m;
+      rowmax[r] = fo;
+      ofo[cblk * 32 + r] = fo;
+    }
   }
-}
-
-__global__ void x2_prep_weight_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int A, int Bn,
-                                      int NCH, int src_ab, int flip, long total) {
-  const float ws = dca_coherent_loadf((const float*)(dst + total));   // written by x2_weight_scale_kernel just before
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+  __syncthreads();
+  const long per_blk = (long)NCH * 27 * NT * 512;     // f16 elements of one output-channel block's images
+  unsigned short* out = dst + cblk * per_blk;
+  for (long idx = tid; idx < per_blk; idx += 1024) {
     const int j = idx & 7, lane = (idx >> 3) & 63;
     long t = idx >> 9;
     const int term = t % NT; t /= NT;
-    const int tap = t % 27; t /= 27;
-    const int chunk = t % NCH;
-    const int cblk = (int)(t / NCH);
-    const int bi = cblk * 32 + (lane & 31), ai = chunk * 16 + 8 * (lane >> 5) + j;
+    const int tap = t % 27;
+    const int chunk = (int)(t / 27);
+    const int r = lane & 31, bi = cblk * 32 + r, ai = chunk * 16 + 8 * (lane >> 5) + j;
     float v = 0.f;
+    int e = 0;
     if (ai < A && bi < Bn) {
       const int st = flip ? 26 - tap : tap;
       v = src_ab ? src[((long)ai * Bn + bi) * 27 + st] : src[((long)bi * A + ai) * 27 + st];
+      e = rowmax[r] - xe[ai];
     }
     _Float16 h, l;
-    split2(v, ws, h, l);
-    dst[idx] = __builtin_bit_cast(unsigned short, term == 0 ? h : l);
+    split2(v, e, h, l);
+    out[idx] = __builtin_bit_cast(unsigned short, term == 0 ? h : l);
   }
-}
-
-// zero-fill of the DCA_AMAX_SLOTS words (a kernel: one node type in captured graphs)
-__global__ void amax_zero_kernel(unsigned* __restrict__ out) { out[blockIdx.x * 256 + threadIdx.x] = 0u; }
-
-// max |x| over a tensor into the DCA_AMAX_SLOTS words of `out` (dca_common.h; zero beforehand): one slot per wave
-__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long n, int vec, unsigned* __restrict__ out) {
-  float m = 0.f;
-  const long stride = (long)gridDim.x * 256;
-  if (vec) {
-    const long n4 = n >> 2;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-      const float4 v = ((const float4*)x)[i];
-      m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-    }
-    for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) m = fmaxf(m, fabsf(x[i]));
-  } else {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) m = fmaxf(m, fabsf(x[i]));
-  }
-  m = wave_max(m);
-  if ((threadIdx.x & 63) == 0) dca_amax_put(out, m, blockIdx.x * 4 + (threadIdx.x >> 6));   // grid <= DCA_AMAX_SLOTS / 4
 }
 
 }  // namespace
 
-// word[DCA_AMAX_SLOTS] <- max |x[0..n)| (its fp32 bit pattern is the maximum over the words): the operand maximum the
-// f16x2 kernels scale by.  Two launches (zero fill of the 32 KB and one read pass); producers that know their output's
-// maximum fill the words themselves (dca_bn_apply, dca_bn_backward, dca_conv3d_x2_forward).
-extern "C" int dca_amax_f32(const float* x, long n, unsigned* word, hipStream_t stream) {
-  DCA_REQUIRE(x && word && n > 0);
-  hipLaunchKernelGGL(amax_zero_kernel, dim3(DCA_AMAX_SLOTS / 256), dim3(256), 0, stream, word);
-  const int vec = (((uintptr_t)x) & 15) == 0;
-  long blocks = (n / 4 + 255) / 256;
-  if (blocks > DCA_AMAX_SLOTS / 4) blocks = DCA_AMAX_SLOTS / 4;
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(amax_kernel, dim3((int)blocks), dim3(256), 0, stream, x, n, vec, word);
-  return dca_launch_status();
-}
-
-// bytes of the packed image: fragments, then 16 bytes {2^ew, 2^-ew, max |w|, 0}
+// bytes of the packed image: fragments, then f_o (one int per output channel, padded to blocks of 32)
 extern "C" long dca_conv3d_x2_weight_bytes(int Cin, int Cout) {
   if (Cin <= 0 || Cout <= 0) return 0;
-  return (long)((Cout + 31) / 32) * ((Cin + 15) / 16) * 27 * NT * 1024 + 16;
+  return (long)((Cout + 31) / 32) * ((Cin + 15) / 16) * 27 * NT * 1024 + (long)((Cout + 31) / 32) * 32 * 4;
 }
 
+// Packs w for ONE convolution launch over an operand with the per-channel scale exponents xexps (A ints).
+//   x_slots == null: xexps is an input (the packed px2 operand's exponents, or a previous call's output);
+//   x_slots != null: the operand's per-channel maxima (slots[c * DCA_AMAX_CSLOTS + s], s < nslots): xexps is derived from
+//                    them and WRITTEN (the weight gradient of the same operand reads it later).
 extern "C" int dca_conv3d_x2_prep_weight(const float* w, void* wx, int A, int B, int src_ab, int flip,
-                                         hipStream_t stream) {
-  DCA_REQUIRE(w && wx && A > 0 && B > 0 && ((((uintptr_t)wx) & 15) == 0));
-  const int NCH = (A + 15) / 16;
-  const long total = (dca_conv3d_x2_weight_bytes(A, B) - 16) / 2;
-  hipLaunchKernelGGL(x2_weight_scale_kernel, dim3(1), dim3(1024), 0, stream, w, (long)A * B * 27,
-                     (float*)((unsigned short*)wx + total));
-  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(x2_prep_weight_kernel, dim3(grid), dim3(256), 0, stream, w, (unsigned short*)wx, A, B, NCH, src_ab,
-                     flip, total);
+                                         const unsigned* x_slots, int nslots, int* xexps, hipStream_t stream) {
+  DCA_REQUIRE(w && wx && xexps && A > 0 && A <= MAX_CIN && B > 0 && ((((uintptr_t)wx) & 15) == 0));
+  DCA_REQUIRE(x_slots == nullptr || (nslots > 0 && nslots <= DCA_AMAX_CSLOTS));
+  const int NCH = (A + 15) / 16, cblks = (B + 31) / 32;
+  int* ofo = (int*)((char*)wx + (long)cblks * NCH * 27 * NT * 1024);
+  hipLaunchKernelGGL(x2_prep_weight_kernel, dim3(cblks), dim3(1024), 0, stream, w, (unsigned short*)wx, A, B, NCH, src_ab,
+                     flip, x_slots, nslots, xexps, x_slots == nullptr ? 1 : 0, ofo);
   return dca_launch_status();
 }
 
@@ -621,57 +699,75 @@ int x2_grid(long tiles, int cblks) {
   }
   int gx = ncu / cblks > 0 ? ncu / cblks : 1;
   if (gx > tiles) gx = (int)tiles;
+  if (gx > DCA_AMAX_CSLOTS) gx = DCA_AMAX_CSLOTS;      // a workgroup index is also a slot of the per-channel output maxima
   return gx;
 }
 
-int x2_launch(const float* x, const unsigned* x_amax, const void* wx, float* y, const float* scale, const float* shift,
-              const float* res_pre, const float* res_post, float slope, double* stat_part, unsigned* y_amax, int N,
+template <bool VEC, bool STATS, int EPI, bool PIN>
+int x2_go(const X2Args& a, int gx, int cblks, int lds, hipStream_t stream) {
+  auto kern = conv3_f16x2_kernel<VEC, STATS, EPI, PIN>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(kern, dim3(gx, cblks), dim3(512), lds, stream, a);
+  return dca_launch_status();
+}
+
+int x2_launch(const void* x, int packed, const int* xexps, const void* wx, float* y, const float* scale, const float* shift,
+              const float* res_pre, const float* res_post, float slope, double* stat_part, unsigned* y_cmax, int N,
               int Cin, int Cout, int D, int H, int W, hipStream_t stream) {
-  DCA_REQUIRE(x && x_amax && wx && y && N > 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0);
+  DCA_REQUIRE(x && wx && y && N > 0 && Cin > 0 && Cin <= MAX_CIN && Cout > 0 && D > 0 && H > 0 && W > 0);
+  DCA_REQUIRE(packed ? (Cin % 8 == 0) : (xexps != nullptr));
   DCA_REQUIRE((scale == nullptr) == (shift == nullptr));
   DCA_REQUIRE((long)Cin * D * H * W * 4 < 0x7ffffff0L && (long)Cout * D * H * W * 4 < 0x7ffffff0L);  // 32-bit byte offsets inside one sample
-  DCA_REQUIRE((((uintptr_t)wx) & 15) == 0 && (((uintptr_t)x_amax) & 3) == 0);
+  DCA_REQUIRE((((uintptr_t)wx) & 15) == 0 && (!packed || (((uintptr_t)x) & 15) == 0));
   X2Args a;
-  a.x = x; a.wx = (const unsigned short*)wx; a.y = y;
+  a.x = (const float*)x; a.wx = (const unsigned short*)wx; a.y = y;
   a.scale = scale; a.shift = shift; a.res_pre = res_pre; a.res_post = res_post; a.slope = slope;
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.NCH = (Cin + 15) / 16;
   a.D = D; a.H = H; a.W = W;
   a.nTD = cdiv(D, TD); a.nTH = cdiv(H, TH); a.nTW = cdiv(W, TW);
   a.stat_part = stat_part;
-  a.x_amax = x_amax;
-  a.y_amax = y_amax;
-  a.wtail = (const float*)((const char*)wx + dca_conv3d_x2_weight_bytes(Cin, Cout) - 16);
+  a.xexps = xexps;
+  a.y_cmax = y_cmax;
+  const int cblks = (Cout + 31) / 32;
+  a.ofo = (const int*)((const char*)wx + (long)cblks * a.NCH * 27 * NT * 1024);
   const long tiles = (long)N * a.nTD * a.nTH * a.nTW;
-  DCA_REQUIRE(tiles < 0x7fffffffL && (Cout + 31) / 32 <= 65535);
+  DCA_REQUIRE(tiles < 0x7fffffffL && cblks <= 65535);
   const bool vec = (W % 4 == 0) && ((((uintptr_t)x) & 15) == 0);
   const bool stats = stat_part != nullptr;
-  const bool epi = scale != nullptr || res_pre != nullptr || res_post != nullptr || slope != 1.f;
+  const bool full = scale != nullptr || res_pre != nullptr || slope != 1.f || y_cmax != nullptr;
+  const int epi = full ? 1 : (res_post != nullptr ? 2 : 0);
   DCA_REQUIRE(!(stats && epi));    // the statistics are those of the raw convolution output
-  auto kern = stats ? (vec ? conv3_f16x2_kernel<true, true, false> : conv3_f16x2_kernel<false, true, false>)
-              : epi ? (vec ? conv3_f16x2_kernel<true, false, true> : conv3_f16x2_kernel<false, false, true>)
-                    : (vec ? conv3_f16x2_kernel<true, false, false> : conv3_f16x2_kernel<false, false, false>);
-  const int lds = LDS_BYTES + (stats ? STAT_LDS : 0);
-  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  if (e != hipSuccess) return (int)e;
-  const int cblks = (Cout + 31) / 32;
-  DCA_REQUIRE(y_amax == nullptr || (long)x2_grid(tiles, cblks) * cblks * 8 <= DCA_AMAX_SLOTS);   // one slot per wave
-  hipLaunchKernelGGL(kern, dim3(x2_grid(tiles, cblks), cblks), dim3(512), lds, stream, a);
-  return dca_launch_status();
+  const int lds = LDS_BYTES + TAB_BYTES + (stats ? STAT_LDS : 0);
+  const int gx = x2_grid(tiles, cblks);
+  if (packed) {
+    DCA_REQUIRE(epi != 1);         // the packed operand exists in training only (BatchNorm kernels write it)
+    if (stats) return x2_go<true, true, 0, true>(a, gx, cblks, lds, stream);
+    if (epi == 2) return x2_go<true, false, 2, true>(a, gx, cblks, lds, stream);
+    return x2_go<true, false, 0, true>(a, gx, cblks, lds, stream);
+  }
+  if (stats) return vec ? x2_go<true, true, 0, false>(a, gx, cblks, lds, stream) : x2_go<false, true, 0, false>(a, gx, cblks, lds, stream);
+  if (epi == 1) return vec ? x2_go<true, false, 1, false>(a, gx, cblks, lds, stream) : x2_go<false, false, 1, false>(a, gx, cblks, lds, stream);
+  if (epi == 2) return vec ? x2_go<true, false, 2, false>(a, gx, cblks, lds, stream) : x2_go<false, false, 2, false>(a, gx, cblks, lds, stream);
+  return vec ? x2_go<true, false, 0, false>(a, gx, cblks, lds, stream) : x2_go<false, false, 0, false>(a, gx, cblks, lds, stream);
 }
 
 }  // namespace
 
 // y = act(conv(x, w) * scale[c] + shift[c] + res_pre) + res_post (the epilogue contract of dca_conv3d_forward) with the
-// f16x2 split arithmetic; x_amax = device word holding the bit pattern of max |x| (dca_amax_f32 or a producer); y_amax
-// (may be null) = zero-initialised device word that receives the bit pattern of max |y| for the consumer of y.
-extern "C" int dca_conv3d_x2_forward(const float* x, const unsigned* x_amax, const void* wx, float* y, const float* scale,
+// f16x2 split arithmetic.  x: fp32 (N,Cin,D,H,W) with xexps = its per-channel scale exponents (Cin ints: output of
+// dca_conv3d_x2_prep_weight / dca_cmax_exps), or packed != 0: the px2 image of that tensor (xexps unused: the exponents
+// are in the packed weights).  wx = dca_conv3d_x2_prep_weight(...) for THIS operand.  y_cmax (may be null): per-channel
+// slots [c][s], s < dca_conv3d_x2_out_slots(...), that receive max |y| for the consumer of y.
+extern "C" int dca_conv3d_x2_forward(const void* x, int packed, const int* xexps, const void* wx, float* y, const float* scale,
                                      const float* shift, const float* res_pre, const float* res_post, float slope,
-                                     unsigned* y_amax, int N, int Cin, int Cout, int D, int H, int W, hipStream_t stream) {
-  return x2_launch(x, x_amax, wx, y, scale, shift, res_pre, res_post, slope, nullptr, y_amax, N, Cin, Cout, D, H, W,
+                                     unsigned* y_cmax, int N, int Cin, int Cout, int D, int H, int W, hipStream_t stream) {
+  return x2_launch(x, packed, xexps, wx, y, scale, shift, res_pre, res_post, slope, nullptr, y_cmax, N, Cin, Cout, D, H, W,
                    stream);
 }
 
-// nchunk of the statistics dca_conv3d_x2_forward_stats produces (one partial per workgroup of the launch it will make)
+// nchunk of the statistics dca_conv3d_x2_forward_stats produces (one partial per workgroup of the launch it will make);
+// also the number of y_cmax slots per channel dca_conv3d_x2_forward fills
 extern "C" long dca_conv3d_x2_stats_chunks(int N, int Cout, int D, int H, int W) {
   if (N <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
   const long tiles = (long)N * cdiv(D, TD) * cdiv(H, TH) * cdiv(W, TW);
@@ -681,10 +777,10 @@ extern "C" long dca_conv3d_x2_stats_chunks(int N, int Cout, int D, int H, int W)
 // y = conv(x, w) (no epilogue) plus the BatchNorm batch statistics of y: part (Cout * nchunk * 4 doubles, nchunk =
 // dca_conv3d_x2_stats_chunks) = one {K, n, sum (y - K), sum (y - K)^2} per (channel, workgroup), for
 // dca_bn_finalize_centered (bn_fused_stats.h)
-extern "C" int dca_conv3d_x2_forward_stats(const float* x, const unsigned* x_amax, const void* wx, float* y,
+extern "C" int dca_conv3d_x2_forward_stats(const void* x, int packed, const int* xexps, const void* wx, float* y,
                                            double* stat_part, int N, int Cin, int Cout, int D, int H, int W,
                                            hipStream_t stream) {
   DCA_REQUIRE(stat_part);
-  return x2_launch(x, x_amax, wx, y, nullptr, nullptr, nullptr, nullptr, 1.f, stat_part, nullptr, N, Cin, Cout, D, H, W,
+  return x2_launch(x, packed, xexps, wx, y, nullptr, nullptr, nullptr, nullptr, 1.f, stat_part, nullptr, N, Cin, Cout, D, H, W,
                    stream);
 }

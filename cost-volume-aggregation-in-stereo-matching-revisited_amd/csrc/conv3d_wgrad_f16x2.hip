@@ -1,6 +1,10 @@
 // Weight gradient of the 3x3x3 stride-1 convolution on the f16 matrix pipe with fp32-grade accuracy (the "f16x2" split of
-// conv3d_f16x2.hip: both operands scaled by a power of two taken from their tensor's max |.|, split into two f16 terms,
-// the three partial products >= 2^-11 accumulated in fp32; the slab written at the end is scaled back).
+// conv3d_f16x2.hip: every CHANNEL of both operands scaled by its own power of two 2^exps[c] -- the channels are the M and N
+// dimensions of this product, so the scales factor out exactly --, split into two f16 terms, the three partial products
+// >= 2^-11 accumulated in fp32; entry (co, ci) of the slab written at the end is scaled back by 2^-(yexps[co] + xexps[ci])).
+// Either operand may arrive in the packed px2 format (dca_common.h: scaled and split by the BatchNorm kernel that wrote
+// it, [voxel][8 channels] words): a thread then loads the 8 words of 8 consecutive voxels and transposes the 8 x 8 block of
+// f16 in registers (32 v_perm_b32) into the [channel][8 voxels] LDS words the fragments are read from.
 //
 //   dW[co][ci][kd,kh,kw] = sum_{n,d,h,w} dy[n][co][d][h][w] * x[n][ci][d+kd-1][h+kh-1][w+kw-1]
 //
@@ -72,21 +76,37 @@ constexpr int NY_ITEMS = NROW * 2 * 32, KY = NY_ITEMS / 512;     // 512  -> 1 pe
 static_assert(NX_ITEMS % 512 == 0 && NY_ITEMS % 512 == 0, "staging items");
 
 struct WX2Args {
-  const float* x;
+  const float* x;           // fp32 (N,Cx,D,H,W) or its px2 image
   const float* dy;
   float* part;
   int N, Cx, Cy, D, H, W;
   int nTD, nTH, nTW, nCxT;
-  const unsigned* x_amax;   // max |x| / max |dy|: DCA_AMAX_SLOTS device words each (dca_common.h)
-  const unsigned* y_amax;
+  const int* xexps;         // per-channel scale exponents of x / dy (Cx / Cy ints, dca_common.h)
+  const int* yexps;
 };
 
-__device__ __forceinline__ void split2(float v, float s, _Float16& h, _Float16& l) {
-  const float u = v * s;          // exact: power of two, scaled maximum < 2^15
+__device__ __forceinline__ void split2(float v, int e, _Float16& h, _Float16& l) {
+  const float u = ldexpf(v, e);   // exact; scaled maximum < 2^15
   h = (_Float16)u;
   l = (_Float16)(u - (float)h);   // the residual is exact in fp32
 }
 
+// 8 x 8 transpose of f16: in[v] = the 8 channels of voxel v (one px2 word), out[c] = the 8 voxels of channel c
+__device__ __forceinline__ void transpose8x8(const u32x4v (&in)[8], u32x4v (&out)[8]) {
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      out[2 * d][i] = __builtin_amdgcn_perm(in[2 * i + 1][d], in[2 * i][d], 0x05040100u);       // low halves: channel 2d
+      out[2 * d + 1][i] = __builtin_amdgcn_perm(in[2 * i + 1][d], in[2 * i][d], 0x07060302u);   // high halves: channel 2d+1
+    }
+}
+
+constexpr int NXU = NT * NHROW * 2 * 4;   // packed x: (term, halo row, k half, channel group) units of 8 words = 384 (threads 0-383)
+constexpr int NYU = NT * NROW * 2 * 4;    // packed dy: 128 units (threads 384-511)
+static_assert(NXU + NYU == 512, "one packed unit per thread");
+
+template <bool XP, bool YP>
 __global__ __launch_bounds__(512) void wgrad3_f16x2_kernel(WX2Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, half = lane >> 5;
@@ -112,13 +132,14 @@ __global__ __launch_bounds__(512) void wgrad3_f16x2_kernel(WX2Args a) {
 
   const int cstride = a.D * a.H * a.W;
   const long xsample = (long)a.Cx * cstride, ysample = (long)a.Cy * cstride;
-  const int xexp = x2_scale_exp(dca_amax_get(a.x_amax));
-  const int yexp = x2_scale_exp(dca_amax_get(a.y_amax));
-  const float xs = x2_pow2(xexp), ys = x2_pow2(yexp);
+  // a thread's fp32 staging items all belong to channel (tid & 31) of the block: one exponent per operand
+  const int xe_t = (cx0 + (tid & 31) < a.Cx) ? dca_coherent_loadi(a.xexps + cx0 + (tid & 31)) : 0;
+  const int ye_t = (cy0 + (tid & 31) < a.Cy) ? dca_coherent_loadi(a.yexps + cy0 + (tid & 31)) : 0;
 
   // staging items: channel fastest (conflict-free LDS writes), then k half / side, then row
-  float4 rx[KX][2], ry[KY][2];
-  float re[KE];
+  float4 rx[XP ? 1 : KX][2], ry[YP ? 1 : KY][2];
+  float re[XP ? 1 : KE];
+  u32x4v pu[(XP || YP) ? 8 : 1], pe;      // packed operand: the 8 words of this thread's unit, the word of its edge voxel
   auto decode = [&](int tile, int& n, int& d0, int& h0, int& w0) __attribute__((always_inline)) {
     const int tw = tile % a.nTW; tile /= a.nTW;
     const int th = tile % a.nTH; tile /= a.nTH;
@@ -129,6 +150,31 @@ __global__ __launch_bounds__(512) void wgrad3_f16x2_kernel(WX2Args a) {
   auto load_tile = [&](int n, int d0, int h0, int w0) __attribute__((always_inline)) {
     const __amdgpu_buffer_rsrc_t xr = dca_rsrc(a.x + (long)n * xsample, xsample * 4);
     const __amdgpu_buffer_rsrc_t yr = dca_rsrc(a.dy + (long)n * ysample, ysample * 4);
+    if constexpr (XP) {
+      if (tid < NXU) {    // unit (term, hrow, k half, group): words of voxels w0 + 8 hf + 0..7; + the edge word of (term, hrow, side, group)
+        const int g = tid & 3, hf = (tid >> 2) & 1, hrow = (tid >> 3) % NHROW, term = tid / (8 * NHROW);
+        const int d = d0 - 1 + hrow / HH, h = h0 - 1 + hrow % HH, w = w0 + 8 * hf, cg = (cx0 >> 3) + g;
+        const int ok = (int)(cg * 8 < a.Cx) & (int)((unsigned)d < (unsigned)a.D) & (int)((unsigned)h < (unsigned)a.H);
+        const int off = term * (a.Cx * cstride * 2) + (cg * cstride + (d * a.H + h) * a.W + w) * 16;
+#pragma unroll
+        for (int v = 0; v < 8; ++v)
+          pu[v] = __builtin_bit_cast(u32x4v, dca_bload4(xr, off + 16 * v, ok & (int)(w + v < a.W)));
+        const int we = hf ? w0 + TW : w0 - 1;     // side = hf
+        pe = __builtin_bit_cast(u32x4v, dca_bload4(xr, off + (we - w) * 16, ok & (int)((unsigned)we < (unsigned)a.W)));
+      }
+    }
+    if constexpr (YP) {
+      if (tid >= NXU) {
+        const int u = tid - NXU, g = u & 3, hf = (u >> 2) & 1, row = (u >> 3) % NROW, term = u / (8 * NROW);
+        const int d = d0 + row / TH, h = h0 + row % TH, w = w0 + 8 * hf, cg = (cy0 >> 3) + g;
+        const int ok = (int)(cg * 8 < a.Cy) & (int)(d < a.D) & (int)(h < a.H);
+        const int off = term * (a.Cy * cstride * 2) + (cg * cstride + (d * a.H + h) * a.W + w) * 16;
+#pragma unroll
+        for (int v = 0; v < 8; ++v)
+          pu[v] = __builtin_bit_cast(u32x4v, dca_bload4(yr, off + 16 * v, ok & (int)(w + v < a.W)));
+      }
+    }
+    if constexpr (!XP) {
 #pragma unroll
     for (int k = 0; k < KX; ++k) {
       const int it = tid + 512 * k, c = it & 31, hf = (it >> 5) & 1, hrow = it >> 6;
@@ -146,6 +192,8 @@ __global__ __launch_bounds__(512) void wgrad3_f16x2_kernel(WX2Args a) {
                      (int)((unsigned)w < (unsigned)a.W);
       re[k] = dca_bload1(xr, ((cx0 + c) * cstride + (d * a.H + h) * a.W + w) * 4, ok);
     }
+    }
+    if constexpr (!YP) {
 #pragma unroll
     for (int k = 0; k < KY; ++k) {
       const int it = tid + 512 * k, c = it & 31, hf = (it >> 5) & 1, row = it >> 6;
@@ -155,8 +203,9 @@ __global__ __launch_bounds__(512) void wgrad3_f16x2_kernel(WX2Args a) {
       ry[k][0] = dca_bload4(yr, off, ok & (int)(w + 3 < a.W));
       ry[k][1] = dca_bload4(yr, off + 16, ok & (int)(w + 7 < a.W));
     }
+    }
   };
-  auto split_store8 = [&](const float4& p, const float4& q, float sc, char* base, int term_stride, int off) __attribute__((always_inline)) {
+  auto split_store8 = [&](const float4& p, const float4& q, int sc, char* base, int term_stride, int off) __attribute__((always_inline)) {
     const float v[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
     f16x8 hv, lv;
 #pragma unroll
@@ -169,19 +218,52 @@ __global__ __launch_bounds__(512) void wgrad3_f16x2_kernel(WX2Args a) {
     *(f16x8*)(base + term_stride + off) = lv;
   };
   auto store_tile = [&]() __attribute__((always_inline)) {
+    if constexpr (XP) {
+      if (tid < NXU) {
+        const int g = tid & 3, hf = (tid >> 2) & 1, hrow = (tid >> 3) % NHROW, term = tid / (8 * NHROW);
+        u32x4v o[8];
+        transpose8x8(pu, o);
+        char* dst = smem + X_OFF + term * X_TERM + ((hrow * 2 + hf) * 32 + g * 8) * 16;      // [hrow][k half][ci][8 voxels]
 #pragma unroll
-    for (int k = 0; k < KX; ++k) split_store8(rx[k][0], rx[k][1], xs, smem + X_OFF, X_TERM, (tid + 512 * k) * 16);
+        for (int c = 0; c < 8; ++c) *(u32x4v*)(dst + c * 16) = o[c];
+        // edge image [hrow][side][ci] dwords: left edge (side 0) in the HIGH half, right edge (side 1) in the LOW half
+        u32x4v e0, e1;
 #pragma unroll
-    for (int k = 0; k < KY; ++k) split_store8(ry[k][0], ry[k][1], ys, smem + Y_OFF, Y_TERM, (tid + 512 * k) * 16);
+        for (int d = 0; d < 4; ++d) {
+          const unsigned lo = pe[d] & 0xffffu, hi = pe[d] >> 16;      // channels 2d, 2d+1 of the group
+          const unsigned a0 = hf ? lo : lo << 16, a1 = hf ? hi : hi << 16;
+          if (d < 2) { e0[2 * d] = a0; e0[2 * d + 1] = a1; } else { e1[2 * d - 4] = a0; e1[2 * d - 3] = a1; }
+        }
+        char* de = smem + XE_OFF + term * XE_TERM + ((hrow * 2 + hf) * 32 + g * 8) * 4;
+        *(u32x4v*)de = e0;
+        *(u32x4v*)(de + 16) = e1;
+      }
+    } else {
 #pragma unroll
-    for (int k = 0; k < KE; ++k) {
-      const int it = tid + 512 * k, side = (it >> 5) & 1;
-      _Float16 h, l;
-      split2(re[k], xs, h, l);
-      // left edge (side 0) sits in the HIGH half of its dword, right edge (side 1) in the LOW half (see shifts below)
-      const unsigned sh = side ? 0 : 16;
-      *(unsigned*)(smem + XE_OFF + it * 4) = (unsigned)__builtin_bit_cast(unsigned short, h) << sh;
-      *(unsigned*)(smem + XE_OFF + XE_TERM + it * 4) = (unsigned)__builtin_bit_cast(unsigned short, l) << sh;
+      for (int k = 0; k < KX; ++k) split_store8(rx[k][0], rx[k][1], xe_t, smem + X_OFF, X_TERM, (tid + 512 * k) * 16);
+#pragma unroll
+      for (int k = 0; k < KE; ++k) {
+        const int it = tid + 512 * k, side = (it >> 5) & 1;
+        _Float16 h, l;
+        split2(re[k], xe_t, h, l);
+        // left edge (side 0) sits in the HIGH half of its dword, right edge (side 1) in the LOW half (see shifts below)
+        const unsigned sh = side ? 0 : 16;
+        *(unsigned*)(smem + XE_OFF + it * 4) = (unsigned)__builtin_bit_cast(unsigned short, h) << sh;
+        *(unsigned*)(smem + XE_OFF + XE_TERM + it * 4) = (unsigned)__builtin_bit_cast(unsigned short, l) << sh;
+      }
+    }
+    if constexpr (YP) {
+      if (tid >= NXU) {
+        const int u = tid - NXU, g = u & 3, hf = (u >> 2) & 1, row = (u >> 3) % NROW, term = u / (8 * NROW);
+        u32x4v o[8];
+        transpose8x8(pu, o);
+        char* dst = smem + Y_OFF + term * Y_TERM + ((row * 2 + hf) * 32 + g * 8) * 16;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) *(u32x4v*)(dst + c * 16) = o[c];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < KY; ++k) split_store8(ry[k][0], ry[k][1], ye_t, smem + Y_OFF, Y_TERM, (tid + 512 * k) * 16);
     }
   };
 
@@ -300,7 +382,15 @@ __global__ __launch_bounds__(512) void wgrad3_f16x2_kernel(WX2Args a) {
     }
   }
 
-  const float inv = x2_pow2(-xexp) * x2_pow2(-yexp);
+  // scale-back: entry (co, ci) by 2^-(yexps[co] + xexps[ci]); ci = this lane's column, co = 16 rows per lane
+  __syncthreads();
+  int* ey_lds = (int*)(smem + LDS_BYTES);
+  if (tid < 32) ey_lds[tid] = (cy0 + tid < a.Cy) ? dca_coherent_loadi(a.yexps + cy0 + tid) : 0;
+  __syncthreads();
+  const int xe_l = (cx0 + l31 < a.Cx) ? dca_coherent_loadi(a.xexps + cx0 + l31) : 0;
+  int ninv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ninv[r] = -(ey_lds[(r & 3) + 8 * (r >> 2) + 4 * half] + xe_l);
 #if WX2_G8
   {  // every wave writes the slab entries of its own taps: part[((blk*nCT + ct)*27 + tap)*1024 + co*32 + ci]
     float* slab = a.part + ((long)blockIdx.x * gridDim.y + ct) * 27 * 1024;
@@ -311,7 +401,7 @@ __global__ __launch_bounds__(512) void wgrad3_f16x2_kernel(WX2Args a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
-          slab[(tap0 + j) * 1024 + co * 32 + l31] = acc[j][r] * inv;
+          slab[(tap0 + j) * 1024 + co * 32 + l31] = ldexpf(acc[j][r], ninv[r]);
         }
       }
     }
@@ -336,7 +426,7 @@ __global__ __launch_bounds__(512) void wgrad3_f16x2_kernel(WX2Args a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
-          slab[tap * 1024 + co * 32 + l31] = (acc[j][r] + red[((wq * 7 + j) * 32 + co) * 32 + l31]) * inv;
+          slab[tap * 1024 + co * 32 + l31] = ldexpf(acc[j][r] + red[((wq * 7 + j) * 32 + co) * 32 + l31], ninv[r]);
         }
       }
     }
@@ -366,26 +456,31 @@ extern "C" long dca_conv3d_wgrad_x2_workspace(int N, int Cx, int Cy, int D, int 
 }
 
 // dw[cy*s_cy + cx*s_cx + tap] = sum dy[cy] * x[cx] shifted by the tap (3x3x3, stride 1, pad 1); x (N,Cx,D,H,W),
-// dy (N,Cy,D,H,W); x_amax / y_amax = device words with the bit patterns of max |x| / max |dy| (dca_amax_f32 or a producer).
-// Requires W % 4 == 0 and 16-byte aligned x / dy (callers fall back to dca_conv3d_wgrad otherwise).
-extern "C" int dca_conv3d_wgrad_x2(const float* x, const unsigned* x_amax, const float* dy, const unsigned* y_amax,
-                                   float* part, float* dw, int N, int Cx, int Cy, int D, int H, int W, long s_cy,
-                                   long s_cx, hipStream_t stream) {
-  DCA_REQUIRE(x && dy && part && dw && x_amax && y_amax && N > 0 && Cx > 0 && Cy > 0 && D > 0 && H > 0 && W > 0);
-  DCA_REQUIRE(W % 4 == 0 && ((((uintptr_t)x | (uintptr_t)dy) & 15) == 0));
+// dy (N,Cy,D,H,W), each fp32 or (x_packed / dy_packed != 0) its px2 image; xexps / yexps = the per-channel scale exponents of
+// x / dy (dca_common.h: from dca_conv3d_x2_prep_weight, dca_cmax_exps or the kernel that wrote the packed image).
+// fp32 operands need W % 4 == 0 and 16-byte alignment (callers fall back to dca_conv3d_wgrad otherwise), packed ones C % 8 == 0.
+extern "C" int dca_conv3d_wgrad_x2(const void* x, int x_packed, const int* xexps, const void* dy, int dy_packed,
+                                   const int* yexps, float* part, float* dw, int N, int Cx, int Cy, int D, int H, int W,
+                                   long s_cy, long s_cx, hipStream_t stream) {
+  DCA_REQUIRE(x && dy && part && dw && xexps && yexps && N > 0 && Cx > 0 && Cy > 0 && D > 0 && H > 0 && W > 0);
+  DCA_REQUIRE(((((uintptr_t)x | (uintptr_t)dy) & 15) == 0));
+  DCA_REQUIRE((x_packed ? Cx % 8 == 0 : W % 4 == 0) && (dy_packed ? Cy % 8 == 0 : W % 4 == 0));
   DCA_REQUIRE((long)Cx * D * H * W * 4 < 0x7ffffff0L && (long)Cy * D * H * W * 4 < 0x7ffffff0L);
   WX2Args a;
-  a.x = x; a.dy = dy; a.part = part; a.x_amax = x_amax; a.y_amax = y_amax; a.N = N; a.Cx = Cx; a.Cy = Cy; a.D = D; a.H = H; a.W = W;
+  a.x = (const float*)x; a.dy = (const float*)dy; a.part = part; a.xexps = xexps; a.yexps = yexps;
+  a.N = N; a.Cx = Cx; a.Cy = Cy; a.D = D; a.H = H; a.W = W;
   a.nTD = cdiv(D, TD); a.nTH = cdiv(H, TH); a.nTW = cdiv(W, TW); a.nCxT = cdiv(Cx, 32);
   const long ntiles = (long)N * a.nTD * a.nTH * a.nTW;
   DCA_REQUIRE(ntiles < 0x7fffffffL);
   const int nCT = a.nCxT * cdiv(Cy, 32);
   DCA_REQUIRE(nCT <= 65535);
   const int nblk = workers(ntiles, nCT);
-  hipError_t e = hipFuncSetAttribute((const void*)wgrad3_f16x2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     LDS_BYTES);
+  const int lds = LDS_BYTES + 128;     // + the 32 exponents of the block's dy channels (end of kernel)
+  auto kern = x_packed ? (dy_packed ? wgrad3_f16x2_kernel<true, true> : wgrad3_f16x2_kernel<true, false>)
+                       : (dy_packed ? wgrad3_f16x2_kernel<false, true> : wgrad3_f16x2_kernel<false, false>);
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(wgrad3_f16x2_kernel, dim3(nblk, nCT), dim3(512), LDS_BYTES, stream, a);
+  hipLaunchKernelGGL(kern, dim3(nblk, nCT), dim3(512), lds, stream, a);
   int st = dca_launch_status();
   if (st) return st;
   return dca_internal_wgrad_reduce(part, dw, nblk, a.nCxT, nCT, 27, Cy, Cx, s_cy, s_cx, stream);

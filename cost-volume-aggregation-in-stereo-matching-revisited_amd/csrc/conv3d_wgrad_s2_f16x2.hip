@@ -74,12 +74,12 @@ struct WS2Args {
   int N, Cx, Cy, D, H, W;        // fine dims
   int Do, Ho, Wo;                // coarse dims
   int nTD, nTH, nTW, nCxT;
-  const unsigned* x_amax;   // max |x| / max |dy|: DCA_AMAX_SLOTS device words each (dca_common.h)
-  const unsigned* y_amax;
+  const int* xexps;         // per-channel scale exponents of the fine / coarse operand (Cx / Cy ints, dca_common.h)
+  const int* yexps;
 };
 
-__device__ __forceinline__ void split2(float v, float s, _Float16& h, _Float16& l) {
-  const float u = v * s;          // exact: power of two, scaled maximum < 2^15
+__device__ __forceinline__ void split2(float v, int s, _Float16& h, _Float16& l) {
+  const float u = ldexpf(v, s);   // exact; scaled maximum < 2^15
   h = (_Float16)u;
   l = (_Float16)(u - (float)h);   // the residual is exact in fp32
 }
@@ -103,9 +103,9 @@ __global__ __launch_bounds__(512) void wgrad3s2_f16x2_kernel(WS2Args a) {
 
   const int cstride = a.D * a.H * a.W, ystride = a.Do * a.Ho * a.Wo;
   const long xsample = (long)a.Cx * cstride, ysample = (long)a.Cy * ystride;
-  const int xexp = x2_scale_exp(dca_amax_get(a.x_amax));
-  const int yexp = x2_scale_exp(dca_amax_get(a.y_amax));
-  const float xs = x2_pow2(xexp), ys = x2_pow2(yexp);
+  // a thread's staging items all belong to channel (tid & 31) of the block: one exponent per operand
+  const int xs = (cx0 + (tid & 31) < a.Cx) ? dca_coherent_loadi(a.xexps + cx0 + (tid & 31)) : 0;
+  const int ys = (cy0 + (tid & 31) < a.Cy) ? dca_coherent_loadi(a.yexps + cy0 + (tid & 31)) : 0;
 
   // staging items: channel fastest (conflict-free LDS writes), then k half, then fine row
   float4 rx[KX][4], ry[2];
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(512) void wgrad3s2_f16x2_kernel(WS2Args a) {
     }
     }
   };
-  auto split_store8 = [&](const float (&v)[8], float sc, char* base, int term_stride, int off) __attribute__((always_inline)) {
+  auto split_store8 = [&](const float (&v)[8], int sc, char* base, int term_stride, int off) __attribute__((always_inline)) {
     f16x8 hv, lv;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -306,7 +306,15 @@ __global__ __launch_bounds__(512) void wgrad3s2_f16x2_kernel(WS2Args a) {
   }
 
   // every wave writes the slab entries of its own taps: part[((blk*nCT + ct)*27 + tap)*1024 + co*32 + ci]
-  const float inv = x2_pow2(-xexp) * x2_pow2(-yexp);
+  // scale-back: entry (co, ci) by 2^-(yexps[co] + xexps[ci])
+  __syncthreads();
+  int* ey_lds = (int*)smem;
+  if (tid < 32) ey_lds[tid] = (cy0 + tid < a.Cy) ? dca_coherent_loadi(a.yexps + cy0 + tid) : 0;
+  __syncthreads();
+  const int xe_l = (cx0 + l31 < a.Cx) ? dca_coherent_loadi(a.xexps + cx0 + l31) : 0;
+  int ninv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ninv[r] = -(ey_lds[(r & 3) + 8 * (r >> 2) + 4 * half] + xe_l);
   {
     float* slab = a.part + ((long)blockIdx.x * gridDim.y + ct) * 27 * 1024;
     const int tap0 = 27 * wq / 8, ntap = 27 * (wq + 1) / 8 - tap0;
@@ -316,7 +324,7 @@ __global__ __launch_bounds__(512) void wgrad3s2_f16x2_kernel(WS2Args a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
-          slab[(tap0 + j) * 1024 + co * 32 + l31] = acc[j][r] * inv;
+          slab[(tap0 + j) * 1024 + co * 32 + l31] = ldexpf(acc[j][r], ninv[r]);
         }
       }
     }
@@ -346,14 +354,14 @@ extern "C" long dca_conv3d_wgrad_s2_x2_workspace(int N, int Cx, int Cy, int D, i
 }
 
 // dw[cy*s_cy + cx*s_cx + tap] = sum_{n, o} c[n][cy][o] * f[n][cx][2 o + tap - 1] (3x3x3, stride 2, pad 1); f (N,Cx,D,H,W),
-// c (N,Cy,(D+1)/2,(H+1)/2,(W+1)/2); f_amax / c_amax = the operands' max-|.| words (DCA_AMAX_SLOTS each).  Requires
+// c (N,Cy,(D+1)/2,(H+1)/2,(W+1)/2); f_exps / c_exps = the operands' per-channel scale exponents (Cx / Cy ints: dca_cmax_exps).  Requires
 // W % 4 == 0, (W+1)/2 % 4 == 0 and 16-byte aligned f / c (callers fall back to dca_conv3d_wgrad otherwise).
-extern "C" int dca_conv3d_wgrad_s2_x2(const float* f, const unsigned* f_amax, const float* c, const unsigned* c_amax,
+extern "C" int dca_conv3d_wgrad_s2_x2(const float* f, const int* f_exps, const float* c, const int* c_exps,
                                       float* part, float* dw, int N, int Cx, int Cy, int D, int H, int W, long s_cy,
                                       long s_cx, hipStream_t stream) {
-  DCA_REQUIRE(f && c && part && dw && f_amax && c_amax && N > 0 && Cx > 0 && Cy > 0 && D > 0 && H > 0 && W > 0);
+  DCA_REQUIRE(f && c && part && dw && f_exps && c_exps && N > 0 && Cx > 0 && Cy > 0 && D > 0 && H > 0 && W > 0);
   WS2Args a;
-  a.x = f; a.dy = c; a.part = part; a.x_amax = f_amax; a.y_amax = c_amax;
+  a.x = f; a.dy = c; a.part = part; a.xexps = f_exps; a.yexps = c_exps;
   a.N = N; a.Cx = Cx; a.Cy = Cy; a.D = D; a.H = H; a.W = W;
   a.Do = (D + 1) / 2; a.Ho = (H + 1) / 2; a.Wo = (W + 1) / 2;
   DCA_REQUIRE(W % 4 == 0 && a.Wo % 4 == 0 && ((((uintptr_t)f | (uintptr_t)c) & 15) == 0));

@@ -94,53 +94,54 @@ __device__ __forceinline__ float4 dca_bload4(__amdgpu_buffer_rsrc_t r, int byte_
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-// ---- operand maxima of the f16x2 kernels (conv3d_f16x2.hip) --------------------------------------------------------------
-// A tensor's max |.| travels as DCA_AMAX_SLOTS zero-initialised device words: every workgroup (or wave) of the producing
-// kernel STORES the bit pattern of its own maximum (a non-negative fp32 number, so unsigned order = float order) into a
-// slot of its own, and the consuming workgroup takes the maximum over all slots.  Plain stores and loads only:
-//  * atomicMax on ONE word serialised thousands of atomics on one address (+45 us on a 150 us BatchNorm pass);
-//  * atomicMax spread over 64 words was fast and correct in eager launches, but inside hipGraph replays the second and
-//    later replays of a graph read wrong maxima (a graph of [zero-fill, amax kernel, convolution] alone reproduced it:
-//    tools/x2_graph_debug4.py) -- the words were right after the replay, the convolution had seen something else.
-#ifndef DCA_AMAX_SLOTS
-#define DCA_AMAX_SLOTS 8192
-#endif
-// slot must be < DCA_AMAX_SLOTS and owned by the caller (one writer per slot and launch)
-__device__ __forceinline__ void dca_amax_put(unsigned* amax, float m, int slot) { amax[slot] = __float_as_uint(m); }
-// maximum over the slots, uniform over the workgroup; EVERY thread of the workgroup must call it (barriers inside)
-__device__ __forceinline__ unsigned dca_amax_get(const unsigned* amax) {
-  __shared__ unsigned dca_amax_red[16];
-  const int nthr = blockDim.x * blockDim.y * blockDim.z, tid = threadIdx.x;
-  unsigned v = 0;
-  for (int i = tid * 4; i < DCA_AMAX_SLOTS; i += nthr * 4) {
-    const uint4 q = *(const uint4*)(amax + i);
-    const unsigned a = q.x > q.y ? q.x : q.y, b = q.z > q.w ? q.z : q.w, m = a > b ? a : b;
-    v = v > m ? v : m;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const unsigned w = (unsigned)__shfl_xor((int)v, o, 64);
-    v = v > w ? v : w;
-  }
-  if ((tid & 63) == 0) dca_amax_red[tid >> 6] = v;
-  __syncthreads();
-  const int nw = (nthr + 63) >> 6;
-  v = dca_amax_red[0];
-  for (int i = 1; i < nw; ++i) v = v > dca_amax_red[i] ? v : dca_amax_red[i];
-  __syncthreads();   // the array may be reused by the next call
-  return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
-}
-// a value another kernel wrote shortly before (the scale tail of a packed weight image), read with a device-coherent
-// vector load instead of an s_load through the scalar data cache
+// ---- operand scales of the f16x2 kernels (conv3d_f16x2.hip, conv3d_wgrad_f16x2.hip, conv3d_wgrad_s2_f16x2.hip) ----------
+// Every operand CHANNEL c is scaled by its own power of two 2^exps[c] that brings the channel's max |.| into [2^14, 2^15)
+// before the split into two f16 terms (round 3: per channel, not per tensor -- a channel 10^8 below the tensor's maximum
+// keeps its 22 bits).  `exps` (C device ints) come from
+//  * per-channel maxima: slots[c * DCA_AMAX_CSLOTS + s], s < nslots -- every workgroup of the producing kernel STORES the
+//    bit pattern of its own maximum over channel c (a non-negative fp32 number, so unsigned order = float order) into a
+//    slot of its own; dca_amax_exps / dca_conv3d_x2_prep_weight take the maximum over the nslots written slots.  Plain
+//    stores and loads only, one writer per slot and launch, nothing to zero-initialise:
+//      - atomicMax on ONE word serialised thousands of atomics on one address (+45 us on a 150 us BatchNorm pass);
+//      - atomicMax spread over 64 words was read WRONGLY inside hipGraph replays (root cause: DESIGN.md section 3,
+//        tools/graph_amax_repro.hip);
+//  * or a bound the producer computes before it writes (the packed "px2" operand format below).
+#define DCA_AMAX_CSLOTS 256
+// a value another kernel wrote shortly before, read with a device-coherent vector load instead of an s_load through the
+// scalar data cache
 __device__ __forceinline__ float dca_coherent_loadf(const float* p) {
   return __uint_as_float(__hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
-// power of two that brings a tensor whose max |.| has the bit pattern `bits` into [2^14, 2^15); 1 for an all-zero tensor.
-// The exponent is clamped to [-100, 60]: beyond that the data are fp32 denormals / infinities and nothing is to be kept.
+__device__ __forceinline__ int dca_coherent_loadi(const int* p) {
+  return (int)__hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// exponent e such that a value whose max |.| has the bit pattern `bits` lands in [2^14, 2^15) after * 2^e; 0 for zero.
+// Clamped to [-100, 126]: scaling is done with v_ldexp_f32 (exact for any e), fp32 denormals are not resolved.
 __device__ __forceinline__ int x2_scale_exp(unsigned bits) {
   const int e = (int)((bits >> 23) & 255);
   int ex = e == 0 ? 0 : 141 - e;
-  ex = ex > 60 ? 60 : (ex < -100 ? -100 : ex);
+  ex = ex > 126 ? 126 : (ex < -100 ? -100 : ex);
   return ex;
 }
-__device__ __forceinline__ float x2_pow2(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
+__device__ __forceinline__ float x2_pow2(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }   // -126 <= e <= 127
+// maximum of a non-negative float over the workgroup -> slot (thread 0 writes); every thread must call it
+__device__ __forceinline__ void dca_cmax_put(float m, unsigned* slot) {
+  m = wave_max(m);
+  __shared__ float dca_cmax_red[16];
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();                       // the array may still be read by a previous call
+  if ((threadIdx.x & 63) == 0) dca_cmax_red[w] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < nw; ++i) m = fmaxf(m, dca_cmax_red[i]);
+    *slot = __float_as_uint(m);
+  }
+}
+
+// ---- packed operand format "px2" -------------------------------------------------------------------------------------
+// An fp32 tensor (N, C, D, H, W), C % 8 == 0, as the two f16 terms the f16x2 kernels multiply, written ONCE by its producer
+// (BatchNorm apply / backward: bandwidth-bound kernels with vector-ALU slack) instead of being scaled, split and transposed
+// by every consumer's staging code:  per sample  [term 2][C/8][D][H][W][8] f16  with  h = f16(x 2^exps[c]), l = f16(x 2^exps[c] - h)
+// -- the same 4 bytes per element as fp32.  A halo voxel's 8 channels are one 16-byte word (the MFMA B fragment of the
+// convolution as it sits in LDS), a halo row is one contiguous run.
+__device__ __forceinline__ long px2_term_bytes(int C, long S) { return (long)C * S * 2; }

@@ -49,12 +49,22 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
   }
 }
 
+// Scale exponent (dca_common.h) of channel c of z = act(gamma * xhat + beta), |slope| <= 1, for batch statistics over `count`
+// elements: no sample lies more than sqrt(count - 1) standard deviations from the batch mean, so |z| <= |gamma| sqrt(count) +
+// |beta| whatever the data -- known BEFORE z is written, which is what lets bn_apply_pack_kernel write the packed operand
+// format in one pass.  The bound is loose (a Gaussian's maximum over 6e6 samples is ~5.3 sigma, the bound 2500): typical
+// values land ~2^9 below the [2^14, 2^15) target, inside the 18 binades over which the two f16 terms keep all 22 bits.
+__device__ __forceinline__ int bn_bound_exp(float gamma, float beta, double count) {
+  const float b = (fabsf(gamma) * sqrtf((float)count) + fabsf(beta)) * 1.0001f;
+  return x2_scale_exp(__float_as_uint(b));
+}
+
 // stats[0..C) mean, [C..2C) invstd, [2C..3C) scale = gamma*invstd, [3C..4C) shift = beta - mean*scale.
 // training: batch statistics (+ running-stat update, momentum m, unbiased variance); otherwise running stats.
 __global__ __launch_bounds__(64) void bn_finalize_kernel(const double* __restrict__ part, int nchunk, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
-                                   float eps, int training, float* __restrict__ stats, int C) {
+                                   float eps, int training, float* __restrict__ stats, int* __restrict__ zexps, int C) {
   const int c = blockIdx.x, lane = threadIdx.x;   // one wave per channel; lanes stride over the chunk partials
   float mean, var;
   if (training) {
@@ -87,6 +97,7 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const double* __restric
   stats[C + c] = invstd;
   stats[2 * C + c] = g * invstd;
   stats[3 * C + c] = b - mean * g * invstd;
+  if (zexps) zexps[c] = bn_bound_exp(g, b, count);
 }
 
 // Training-mode finalize for the statistics the convolution kernels emit themselves (dca_*_forward_stats): partial i of
@@ -96,7 +107,7 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const double* __restric
 __global__ __launch_bounds__(64) void bn_finalize_centered_kernel(const double* __restrict__ part, int nchunk,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
-                                   float eps, float* __restrict__ stats, int C) {
+                                   float eps, float* __restrict__ stats, int* __restrict__ zexps, int C) {
   const int c = blockIdx.x, lane = threadIdx.x;
   const double* p = part + (long)c * nchunk * 4;
   const double kref = p[0];
@@ -127,71 +138,157 @@ __global__ __launch_bounds__(64) void bn_finalize_centered_kernel(const double* 
   stats[C + c] = invstd;
   stats[2 * C + c] = g * invstd;
   stats[3 * C + c] = b - mean * g * invstd;
+  if (zexps) zexps[c] = bn_bound_exp(g, b, n);
 }
 
-// The f16x2 convolution kernels (conv3d_f16x2.hip) scale their operands by a power of two taken from the tensor's max |.|;
-// the kernels that PRODUCE those operands (bn_apply: activations, bn_bwd_apply: gradients) emit it on the way: every
-// workgroup stores its maximum into its own slot of `amax` (DCA_AMAX_SLOTS words, dca_common.h; zero-initialised, or null).
-__device__ __forceinline__ void amax_emit(float m, unsigned* amax) {
-  m = wave_max(m);
-  __shared__ float amax_red[16];
-  const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) amax_red[w] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int nw = (blockDim.x + 63) >> 6;
-    for (int i = 1; i < nw; ++i) m = fmaxf(m, amax_red[i]);
-    dca_amax_put(amax, m, blockIdx.x);      // ew_grid() <= DCA_AMAX_SLOTS workgroups
+// The f16x2 convolution kernels scale every operand CHANNEL by a power of two taken from the channel's max |.|
+// (dca_common.h); the kernels that PRODUCE those operands (bn_apply: activations, bn_bwd_apply: gradients) emit the maxima on
+// the way: block (chunk ch, channel c) stores its maximum into slot [c][ch] (nchunk <= DCA_AMAX_CSLOTS), or they write the
+// operand in the packed px2 format directly (the *_pack kernels), scaled by exponents the finalize kernels derive from bounds.
+
+// z = act(scale[c]*y + shift[c] + res_pre) + res_post.  Block (ch, c): chunk ch of channel c, all samples.
+// zmax / ymax (may be null): per-channel slots that receive max |z| and max |y - mean| (the latter bounds |xhat| for the
+// gradient's scale in the backward pass).
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ y, const float* __restrict__ stats,
+                                                       const float* __restrict__ res_pre, const float* __restrict__ res_post,
+                                                       float* __restrict__ z, int N, int C, long S, long chunk_len,
+                                                       float slope, int vec, unsigned* __restrict__ zmax,
+                                                       unsigned* __restrict__ ymax) {
+  const int c = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+  const long s0 = ch * chunk_len, s1 = min(S, s0 + chunk_len);
+  const float mean = stats[c], sc = stats[2 * C + c], sh = stats[3 * C + c];
+  float am = 0.f, ym = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const long base = ((long)n * C + c) * S;
+    if (vec) {
+      for (long i = s0 + 4 * tid; i < s1; i += 1024) {
+        float4 v = *(const float4*)(y + base + i);
+        ym = fmaxf(fmaxf(ym, fmaxf(fabsf(v.x - mean), fabsf(v.y - mean))), fmaxf(fabsf(v.z - mean), fabsf(v.w - mean)));
+        v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+        if (res_pre) { const float4 r = *(const float4*)(res_pre + base + i); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+        v.x = act_apply(v.x, slope); v.y = act_apply(v.y, slope); v.z = act_apply(v.z, slope); v.w = act_apply(v.w, slope);
+        if (res_post) { const float4 r = *(const float4*)(res_post + base + i); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+        *(float4*)(z + base + i) = v;
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+      }
+    } else {
+      for (long i = s0 + tid; i < s1; i += 256) {
+        const float yv = y[base + i];
+        ym = fmaxf(ym, fabsf(yv - mean));
+        float v = yv * sc + sh;
+        if (res_pre) v += res_pre[base + i];
+        v = act_apply(v, slope);
+        if (res_post) v += res_post[base + i];
+        z[base + i] = v;
+        am = fmaxf(am, fabsf(v));
+      }
+    }
+  }
+  if (zmax) dca_cmax_put(am, zmax + (long)c * DCA_AMAX_CSLOTS + ch);
+  if (ymax) dca_cmax_put(ym, ymax + (long)c * DCA_AMAX_CSLOTS + ch);
+}
+
+// x 2^e = h + l (+ <= 2^-22 relative): the two f16 terms of the f16x2 kernels
+__device__ __forceinline__ void px2_split(float v, int e, unsigned short& h, unsigned short& l) {
+  const float u = ldexpf(v, e);       // exact
+  const _Float16 hh = (_Float16)u;
+  const _Float16 ll = (_Float16)(u - (float)hh);   // the residual is exact in fp32
+  h = __builtin_bit_cast(unsigned short, hh);
+  l = __builtin_bit_cast(unsigned short, ll);
+}
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
+// The same BatchNorm apply (no residuals) writing z in the packed px2 operand format (dca_common.h) for the f16x2
+// convolution that consumes it: block (ch, cg) = chunk ch of the 8-channel group cg, all samples; a lane takes ONE voxel and
+// its 8 channels (eight 4-byte loads, each 256 contiguous bytes per wave; two 16-byte stores, 1 KB contiguous per wave).
+// stats == null: identity (plain packing of an fp32 tensor, dca_pack_x2).
+__global__ __launch_bounds__(256) void bn_apply_pack_kernel(const float* __restrict__ y, const float* __restrict__ stats,
+                                                            const int* __restrict__ zexps, char* __restrict__ zp, int N,
+                                                            int C, long S, long chunk_len, float slope,
+                                                            unsigned* __restrict__ ymax) {
+  const int cg = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+  const long s0 = ch * chunk_len, s1 = min(S, s0 + chunk_len);
+  float mean[8], sc[8], sh[8], ym[8];
+  int ex[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cg * 8 + j;
+    mean[j] = stats ? stats[c] : 0.f;
+    sc[j] = stats ? stats[2 * C + c] : 1.f;
+    sh[j] = stats ? stats[3 * C + c] : 0.f;
+    ex[j] = dca_coherent_loadi(zexps + c);
+    ym[j] = 0.f;
+  }
+  const long tb = px2_term_bytes(C, S);
+  for (int n = 0; n < N; ++n) {
+    const float* yb = y + ((long)n * C + cg * 8) * S;
+    char* zb = zp + (long)n * 2 * tb + (long)cg * S * 16;
+    for (long i = s0 + tid; i < s1; i += 256) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = yb[j * S + i];
+      u16x8 hv, lv;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        ym[j] = fmaxf(ym[j], fabsf(v[j] - mean[j]));
+        const float zz = act_apply(v[j] * sc[j] + sh[j], slope);
+        unsigned short h, l;
+        px2_split(zz, ex[j], h, l);
+        hv[j] = h; lv[j] = l;
+      }
+      *(u16x8*)(zb + i * 16) = hv;
+      *(u16x8*)(zb + tb + i * 16) = lv;
+    }
+  }
+  if (ymax) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dca_cmax_put(ym[j], ymax + (long)(cg * 8 + j) * DCA_AMAX_CSLOTS + ch);
   }
 }
 
-// z = act(scale[c]*y + shift[c] + res_pre) + res_post
-__global__ void bn_apply_kernel(const float* __restrict__ y, const float* __restrict__ stats,
-                                const float* __restrict__ res_pre, const float* __restrict__ res_post,
-                                float* __restrict__ z, int C, long S, long total, float slope, int vec,
-                                unsigned* __restrict__ amax) {
-  const float* scale = stats + 2 * C;
-  const float* shift = stats + 3 * C;
-  float am = 0.f;
-  if (vec) {
-    const long total4 = total >> 2;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
-      const int c = (int)((i * 4 / S) % C);
-      const float sc = scale[c], sh = shift[c];
-      float4 v = ((const float4*)y)[i];
-      v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
-      if (res_pre) { const float4 r = ((const float4*)res_pre)[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
-      v.x = act_apply(v.x, slope); v.y = act_apply(v.y, slope); v.z = act_apply(v.z, slope); v.w = act_apply(v.w, slope);
-      if (res_post) { const float4 r = ((const float4*)res_post)[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
-      ((float4*)z)[i] = v;
-      am = fmaxf(fmaxf(am, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-    }
-  } else {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-      const int c = (int)((i / S) % C);
-      float v = y[i] * scale[c] + shift[c];
-      if (res_pre) v += res_pre[i];
-      v = act_apply(v, slope);
-      if (res_post) v += res_post[i];
-      z[i] = v;
-      am = fmaxf(am, fabsf(v));
+// per-channel max |x| of an fp32 tensor into slots [c][ch] (the read pass for operands whose producer emits nothing)
+__global__ __launch_bounds__(256) void cmax_kernel(const float* __restrict__ x, int N, int C, long S, long chunk_len, int vec,
+                                                   unsigned* __restrict__ slots) {
+  const int c = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+  const long s0 = ch * chunk_len, s1 = min(S, s0 + chunk_len);
+  float m = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const float* p = x + ((long)n * C + c) * S;
+    if (vec) {
+      for (long i = s0 + 4 * tid; i < s1; i += 1024) {
+        const float4 v = *(const float4*)(p + i);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+      }
+    } else {
+      for (long i = s0 + tid; i < s1; i += 256) m = fmaxf(m, fabsf(p[i]));
     }
   }
-  if (amax) amax_emit(am, amax);
+  dca_cmax_put(m, slots + (long)c * DCA_AMAX_CSLOTS + ch);
+}
+
+// exps[c] = exponent that brings max over the channel's nslots slot maxima into [2^14, 2^15); one wave per channel
+__global__ __launch_bounds__(64) void cmax_exps_kernel(const unsigned* __restrict__ slots, int nslots, int* __restrict__ exps) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  unsigned v = 0;
+  for (int i = lane; i < nslots; i += 64) { const unsigned u = slots[(long)c * DCA_AMAX_CSLOTS + i]; v = v > u ? v : u; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const unsigned u = (unsigned)__shfl_xor((int)v, o, 64); v = v > u ? v : u; }
+  if (lane == 0) exps[c] = x2_scale_exp(v);
 }
 
 // ------------------------------------------------------------------------------------ BN backward
 // u = scale*y + shift (+res_pre); g = dz * (u > 0 ? 1 : slope); xhat = (y - mean)*invstd
-// part = per-(channel, chunk) double sums of (g, g*xhat).
+// part = per-(channel, chunk) double sums of (g, g*xhat); gmax (may be null): per-channel slots [c][ch] with max |g|.
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dz, const float* __restrict__ y,
                                                             const float* __restrict__ res_pre,
                                                             const float* __restrict__ stats,
                                                             double* __restrict__ part, int N, int C, long S,
-                                                            int nchunk, long chunk_len, float slope, int vec) {
+                                                            int nchunk, long chunk_len, float slope, int vec,
+                                                            unsigned* __restrict__ gmax) {
   const int c = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
   const long s0 = ch * chunk_len, s1 = min(S, s0 + chunk_len);
   const float mean = stats[c], invstd = stats[C + c], sc = stats[2 * C + c], sh = stats[3 * C + c];
-  float a0 = 0.f, a1 = 0.f;
+  float a0 = 0.f, a1 = 0.f, gm = 0.f;
   for (int n = 0; n < N; ++n) {
     const long base = ((long)n * C + c) * S;
     if (vec) {
@@ -207,6 +304,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
           const float g = ds[j] * (u > 0.f ? 1.f : slope);
           a0 += g;
           a1 += g * (ys[j] - mean) * invstd;
+          gm = fmaxf(gm, fabsf(g));
         }
       }
     } else {
@@ -217,6 +315,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         const float g = dz[base + i] * (u > 0.f ? 1.f : slope);
         a0 += g;
         a1 += g * (yv - mean) * invstd;
+        gm = fmaxf(gm, fabsf(g));
       }
     }
   }
@@ -228,11 +327,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     part[((long)c * nchunk + ch) * 2 + 0] = red[0] + red[2] + red[4] + red[6];
     part[((long)c * nchunk + ch) * 2 + 1] = red[1] + red[3] + red[5] + red[7];
   }
+  if (gmax) dca_cmax_put(gm, gmax + (long)c * DCA_AMAX_CSLOTS + ch);
 }
 
-// dgb[0..C) = dgamma, dgb[C..2C) = dbeta, dgb[2C..3C) = dbeta/count, dgb[3C..4C) = dgamma/count
+// dgb[0..C) = dgamma, dgb[C..2C) = dbeta, dgb[2C..3C) = dbeta/count, dgb[3C..4C) = dgamma/count.
+// dyexps (may be null): the scale exponent of channel c of dy = scale (g - dbeta/count - xhat dgamma/count) from the bound
+// |dy| <= |scale| (max|g| + |dbeta/count| + max|xhat| |dgamma/count|), max |g| from gmax (this launch's reduce pass),
+// max |xhat| = invstd * max|y - mean| from ymax (the forward apply pass; null: sqrt(count), the largest |xhat| a sample can have).
 __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* __restrict__ part, int nchunk, double count,
-                                       float* __restrict__ dgb, int C) {
+                                       float* __restrict__ dgb, int C, const float* __restrict__ stats, int training,
+                                       const unsigned* __restrict__ gmax, const unsigned* __restrict__ ymax, int ymax_slots,
+                                       int* __restrict__ dyexps) {
   const int c = blockIdx.x, lane = threadIdx.x;
   double s0 = 0.0, s1 = 0.0;
   for (int i = lane; i < nchunk; i += 64) {
@@ -241,58 +346,120 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* __res
   }
   s0 = wave_sum_d(s0);
   s1 = wave_sum_d(s1);
+  unsigned gmb = 0, ymb = 0;
+  if (dyexps) {
+    for (int i = lane; i < nchunk; i += 64) { const unsigned u = gmax[(long)c * DCA_AMAX_CSLOTS + i]; gmb = gmb > u ? gmb : u; }
+    if (ymax)
+      for (int i = lane; i < ymax_slots; i += 64) { const unsigned u = ymax[(long)c * DCA_AMAX_CSLOTS + i]; ymb = ymb > u ? ymb : u; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned u = (unsigned)__shfl_xor((int)gmb, o, 64), w = (unsigned)__shfl_xor((int)ymb, o, 64);
+      gmb = gmb > u ? gmb : u;
+      ymb = ymb > w ? ymb : w;
+    }
+  }
   if (lane != 0) return;
   dgb[c] = (float)s1;
   dgb[C + c] = (float)s0;
   dgb[2 * C + c] = (float)(s0 / count);
   dgb[3 * C + c] = (float)(s1 / count);
+  if (dyexps) {
+    const float invstd = stats[C + c], sc = fabsf(stats[2 * C + c]);
+    const float xh = ymax ? __uint_as_float(ymb) * invstd : sqrtf((float)count);
+    float bound = __uint_as_float(gmb);
+    if (training) bound += fabsf((float)(s0 / count)) + xh * fabsf((float)(s1 / count));
+    dyexps[c] = x2_scale_exp(__float_as_uint(bound * sc * 1.0001f));
+  }
 }
 
 // dy = scale * (g - [training](dbeta/count + xhat*dgamma/count)); optionally g_out = g (grad of res_pre).
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ y,
+// Block (ch, c) as bn_apply_kernel; dmax (may be null): per-channel slots receiving max |dy|.
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ y,
                                     const float* __restrict__ res_pre, const float* __restrict__ stats,
                                     const float* __restrict__ dgb, float* __restrict__ dy, float* __restrict__ g_out,
-                                    int C, long S, long total, float slope, int training, int vec,
-                                    unsigned* __restrict__ amax) {
+                                    int N, int C, long S, long chunk_len, float slope, int training, int vec,
+                                    unsigned* __restrict__ dmax) {
+  const int c = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+  const long s0 = ch * chunk_len, s1 = min(S, s0 + chunk_len);
+  const float mean = stats[c], invstd = stats[C + c], sc = stats[2 * C + c], sh = stats[3 * C + c];
+  const float k1 = training ? dgb[2 * C + c] : 0.f, k2 = training ? dgb[3 * C + c] * invstd : 0.f;
   float am = 0.f;
-  if (vec) {
-    const long total4 = total >> 2;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
-      const int c = (int)((i * 4 / S) % C);
-      const float mean = stats[c], invstd = stats[C + c], sc = stats[2 * C + c], sh = stats[3 * C + c];
-      const float k1 = training ? dgb[2 * C + c] : 0.f, k2 = training ? dgb[3 * C + c] * invstd : 0.f;
-      const float4 yv = ((const float4*)y)[i], dv = ((const float4*)dz)[i];
-      float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (res_pre) rv = ((const float4*)res_pre)[i];
-      const float ys[4] = {yv.x, yv.y, yv.z, yv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w}, rs[4] = {rv.x, rv.y, rv.z, rv.w};
-      float o[4], g[4];
+  for (int n = 0; n < N; ++n) {
+    const long base = ((long)n * C + c) * S;
+    if (vec) {
+      for (long i = s0 + 4 * tid; i < s1; i += 1024) {
+        const float4 yv = *(const float4*)(y + base + i), dv = *(const float4*)(dz + base + i);
+        float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (res_pre) rv = *(const float4*)(res_pre + base + i);
+        const float ys[4] = {yv.x, yv.y, yv.z, yv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w}, rs[4] = {rv.x, rv.y, rv.z, rv.w};
+        float o[4], g[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float u = ys[j] * sc + sh + rs[j];
-        g[j] = ds[j] * (u > 0.f ? 1.f : slope);
-        o[j] = (g[j] - k1 - (ys[j] - mean) * k2) * sc;
+        for (int j = 0; j < 4; ++j) {
+          const float u = ys[j] * sc + sh + rs[j];
+          g[j] = ds[j] * (u > 0.f ? 1.f : slope);
+          o[j] = (g[j] - k1 - (ys[j] - mean) * k2) * sc;
+        }
+        *(float4*)(dy + base + i) = make_float4(o[0], o[1], o[2], o[3]);
+        if (g_out) *(float4*)(g_out + base + i) = make_float4(g[0], g[1], g[2], g[3]);
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
       }
-      ((float4*)dy)[i] = make_float4(o[0], o[1], o[2], o[3]);
-      if (g_out) ((float4*)g_out)[i] = make_float4(g[0], g[1], g[2], g[3]);
-      am = fmaxf(fmaxf(am, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+    } else {
+      for (long i = s0 + tid; i < s1; i += 256) {
+        const float yv = y[base + i];
+        float u = yv * sc + sh;
+        if (res_pre) u += res_pre[base + i];
+        const float g = dz[base + i] * (u > 0.f ? 1.f : slope);
+        float v = g;
+        if (training) v -= dgb[2 * C + c] + (yv - mean) * invstd * dgb[3 * C + c];
+        dy[base + i] = v * sc;
+        if (g_out) g_out[base + i] = g;
+        am = fmaxf(am, fabsf(v * sc));
+      }
     }
-    if (amax) amax_emit(am, amax);
-    return;
   }
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)((i / S) % C);
-    const float mean = stats[c], invstd = stats[C + c], sc = stats[2 * C + c], sh = stats[3 * C + c];
-    const float yv = y[i];
-    float u = yv * sc + sh;
-    if (res_pre) u += res_pre[i];
-    const float g = dz[i] * (u > 0.f ? 1.f : slope);
-    float v = g;
-    if (training) v -= dgb[2 * C + c] + (yv - mean) * invstd * dgb[3 * C + c];
-    dy[i] = v * sc;
-    if (g_out) g_out[i] = g;
-    am = fmaxf(am, fabsf(v * sc));
+  if (dmax) dca_cmax_put(am, dmax + (long)c * DCA_AMAX_CSLOTS + ch);
+}
+
+// The same (no res_pre, no g_out) writing dy in the packed px2 format with the exponents of bn_bwd_finalize_kernel: block
+// (ch, cg) and lane = one voxel x 8 channels as in bn_apply_pack_kernel.
+__global__ __launch_bounds__(256) void bn_bwd_apply_pack_kernel(const float* __restrict__ dz, const float* __restrict__ y,
+                                    const float* __restrict__ stats, const float* __restrict__ dgb,
+                                    const int* __restrict__ dyexps, char* __restrict__ dyp, int N, int C, long S,
+                                    long chunk_len, float slope, int training) {
+  const int cg = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+  const long s0 = ch * chunk_len, s1 = min(S, s0 + chunk_len);
+  float mean[8], sc[8], sh[8], k1[8], k2[8];
+  int ex[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cg * 8 + j;
+    mean[j] = stats[c]; sc[j] = stats[2 * C + c]; sh[j] = stats[3 * C + c];
+    k1[j] = training ? dca_coherent_loadf(dgb + 2 * C + c) : 0.f;
+    k2[j] = training ? dca_coherent_loadf(dgb + 3 * C + c) * stats[C + c] : 0.f;
+    ex[j] = dca_coherent_loadi(dyexps + c);
   }
-  if (amax) amax_emit(am, amax);
+  const long tb = px2_term_bytes(C, S);
+  for (int n = 0; n < N; ++n) {
+    const long base = ((long)n * C + cg * 8) * S;
+    char* ob = dyp + (long)n * 2 * tb + (long)cg * S * 16;
+    for (long i = s0 + tid; i < s1; i += 256) {
+      float yv[8], dv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { yv[j] = y[base + j * S + i]; dv[j] = dz[base + j * S + i]; }
+      u16x8 hv, lv;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float u = yv[j] * sc[j] + sh[j];
+        const float g = dv[j] * (u > 0.f ? 1.f : slope);
+        const float o = (g - k1[j] - (yv[j] - mean[j]) * k2[j]) * sc[j];
+        unsigned short h, l;
+        px2_split(o, ex[j], h, l);
+        hv[j] = h; lv[j] = l;
+      }
+      *(u16x8*)(ob + i * 16) = hv;
+      *(u16x8*)(ob + tb + i * 16) = lv;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------ AvgPool3d(3, 2, 1)
@@ -686,11 +853,12 @@ static int ew_grid(long total) {
   long g = (total + 255) / 256;
   return (int)(g < 8192 ? (g > 0 ? g : 1) : 8192);
 }
-static_assert(DCA_AMAX_SLOTS >= 8192, "bn_apply / bn_bwd_apply: one operand-maximum slot per workgroup");
 
 static void chunking(long S, int C, int* nchunk, long* chunk_len) {
-  // enough blocks to fill 256 CUs a few times over, chunks a multiple of 1024 floats
+  // enough blocks to fill 256 CUs a few times over, chunks a multiple of 1024 floats; at most DCA_AMAX_CSLOTS chunks (a
+  // chunk index is also a slot of the per-channel operand maxima)
   long want = (2048 + C - 1) / C;
+  if (want > DCA_AMAX_CSLOTS) want = DCA_AMAX_CSLOTS;
   long len = (S + want - 1) / want;
   len = ((len + 1023) / 1024) * 1024;
   *chunk_len = len;
@@ -700,6 +868,12 @@ static void chunking(long S, int C, int* nchunk, long* chunk_len) {
 extern "C" int dca_bn_num_chunks(int C, long S) {
   int n; long l;
   chunking(S, C, &n, &l);
+  return n;
+}
+// chunks (= slots per channel) of the 8-channel-group kernels that write the packed px2 format
+extern "C" int dca_bn_pack_chunks(int C, long S) {
+  int n; long l;
+  chunking(S, (C + 7) / 8, &n, &l);
   return n;
 }
 
@@ -714,48 +888,98 @@ extern "C" int dca_bn_stats(const float* x, double* part, int N, int C, long S, 
 
 extern "C" int dca_bn_finalize(const double* part, int nchunk, double count, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, float momentum, float eps, int training,
-                               float* stats, int C, hipStream_t stream) {
+                               float* stats, int* zexps, int C, hipStream_t stream) {
   DCA_REQUIRE(stats && C > 0 && (training ? (part != nullptr && nchunk > 0) : (running_mean && running_var)));
+  DCA_REQUIRE(zexps == nullptr || training);      // the bound behind zexps holds for batch statistics only
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, stream, part, nchunk, count, gamma, beta,
-                     running_mean, running_var, momentum, eps, training, stats, C);
+                     running_mean, running_var, momentum, eps, training, stats, zexps, C);
   return dca_launch_status();
 }
 
 extern "C" int dca_bn_finalize_centered(const double* part, int nchunk, const float* gamma, const float* beta,
                                         float* running_mean, float* running_var, float momentum, float eps, float* stats,
-                                        int C, hipStream_t stream) {
+                                        int* zexps, int C, hipStream_t stream) {
   DCA_REQUIRE(part && nchunk > 0 && stats && C > 0 && ((running_mean == nullptr) == (running_var == nullptr)));
   hipLaunchKernelGGL(bn_finalize_centered_kernel, dim3(C), dim3(64), 0, stream, part, nchunk, gamma, beta, running_mean,
-                     running_var, momentum, eps, stats, C);
+                     running_var, momentum, eps, stats, zexps, C);
   return dca_launch_status();
 }
 
 extern "C" int dca_bn_apply(const float* y, const float* stats, const float* res_pre, const float* res_post, float* z,
-                            int N, int C, long S, float slope, unsigned* amax, hipStream_t stream) {
-  DCA_REQUIRE(y && stats && z && N > 0 && C > 0 && S > 0);
-  const long total = (long)N * C * S;
+                            int N, int C, long S, float slope, unsigned* zmax, unsigned* ymax, hipStream_t stream) {
+  DCA_REQUIRE(y && stats && z && N > 0 && C > 0 && S > 0 && C <= 65535);
+  int nchunk; long len;
+  chunking(S, C, &nchunk, &len);
   const uintptr_t al = (uintptr_t)y | (uintptr_t)z | (uintptr_t)res_pre | (uintptr_t)res_post;
   const int vec = (S % 4 == 0) && ((al & 15) == 0);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(vec ? total / 4 : total)), dim3(256), 0, stream, y, stats, res_pre,
-                     res_post, z, C, S, total, slope, vec, amax);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(nchunk, C), dim3(256), 0, stream, y, stats, res_pre, res_post, z, N, C, S, len,
+                     slope, vec, zmax, ymax);
+  return dca_launch_status();
+}
+
+extern "C" int dca_bn_apply_pack(const float* y, const float* stats, const int* zexps, void* zp, int N, int C, long S,
+                                 float slope, unsigned* ymax, hipStream_t stream) {
+  DCA_REQUIRE(y && zexps && zp && N > 0 && C > 0 && C % 8 == 0 && S > 0 && C / 8 <= 65535 && ((((uintptr_t)zp) & 15) == 0));
+  DCA_REQUIRE(stats != nullptr || (ymax == nullptr && slope == 1.f));
+  int nchunk; long len;
+  chunking(S, C / 8, &nchunk, &len);
+  hipLaunchKernelGGL(bn_apply_pack_kernel, dim3(nchunk, C / 8), dim3(256), 0, stream, y, stats, zexps, (char*)zp, N, C, S,
+                     len, slope, ymax);
+  return dca_launch_status();
+}
+
+extern "C" int dca_cmax_f32(const float* x, int N, int C, long S, unsigned* slots, hipStream_t stream) {
+  DCA_REQUIRE(x && slots && N > 0 && C > 0 && S > 0 && C <= 65535);
+  int nchunk; long len;
+  chunking(S, C, &nchunk, &len);
+  const int vec = (S % 4 == 0) && ((((uintptr_t)x) & 15) == 0);
+  hipLaunchKernelGGL(cmax_kernel, dim3(nchunk, C), dim3(256), 0, stream, x, N, C, S, len, vec, slots);
+  return dca_launch_status();
+}
+
+extern "C" int dca_cmax_exps(const unsigned* slots, int nslots, int C, int* exps, hipStream_t stream) {
+  DCA_REQUIRE(slots && exps && C > 0 && nslots > 0 && nslots <= DCA_AMAX_CSLOTS);
+  hipLaunchKernelGGL(cmax_exps_kernel, dim3(C), dim3(64), 0, stream, slots, nslots, exps);
   return dca_launch_status();
 }
 
 extern "C" int dca_bn_backward(const float* dz, const float* y, const float* res_pre, const float* stats,
                                double* part, float* dgb, float* dy, float* g_out, int N, int C, long S, float slope,
-                               int training, unsigned* amax, hipStream_t stream) {
+                               int training, unsigned* dmax, hipStream_t stream) {
   DCA_REQUIRE(dz && y && stats && part && dgb && dy && N > 0 && C > 0 && S > 0 && C <= 65535);
   int nchunk; long len;
   chunking(S, C, &nchunk, &len);
   const uintptr_t al = (uintptr_t)dz | (uintptr_t)y | (uintptr_t)res_pre | (uintptr_t)dy | (uintptr_t)g_out;
   const int vec = (S % 4 == 0) && ((al & 15) == 0);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, nchunk), dim3(256), 0, stream, dz, y, res_pre, stats, part, N, C, S,
-                     nchunk, len, slope, vec);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, stream, part, nchunk,
-                     (double)N * (double)S, dgb, C);
-  const long total = (long)N * C * S;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(vec ? total / 4 : total)), dim3(256), 0, stream, dz, y, res_pre,
-                     stats, dgb, dy, g_out, C, S, total, slope, training, vec, amax);
+                     nchunk, len, slope, vec, (unsigned*)nullptr);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, stream, part, nchunk, (double)N * (double)S, dgb, C,
+                     stats, training, (const unsigned*)nullptr, (const unsigned*)nullptr, 0, (int*)nullptr);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nchunk, C), dim3(256), 0, stream, dz, y, res_pre, stats, dgb, dy, g_out, N, C,
+                     S, len, slope, training, vec, dmax);
+  return dca_launch_status();
+}
+
+// BatchNorm backward (no res_pre) writing dy in the packed px2 format: dyp (N*C*S*4 bytes), dyexps (C ints, out) = the
+// per-channel exponents dy was scaled by, from the bound of bn_bwd_finalize_kernel; gmax = scratch of C * DCA_AMAX_CSLOTS
+// words; ymax / ymax_slots = the per-channel max |y - mean| slots the forward apply pass emitted (may be null / 0).
+extern "C" int dca_bn_backward_pack(const float* dz, const float* y, const float* stats, double* part, float* dgb, void* dyp,
+                                    int* dyexps, unsigned* gmax, const unsigned* ymax, int ymax_slots, int N, int C, long S,
+                                    float slope, int training, hipStream_t stream) {
+  DCA_REQUIRE(dz && y && stats && part && dgb && dyp && dyexps && gmax && N > 0 && C > 0 && C % 8 == 0 && S > 0 && C <= 65535);
+  DCA_REQUIRE((ymax == nullptr || (ymax_slots > 0 && ymax_slots <= DCA_AMAX_CSLOTS)) && ((((uintptr_t)dyp) & 15) == 0));
+  int nchunk; long len;
+  chunking(S, C, &nchunk, &len);
+  const uintptr_t al = (uintptr_t)dz | (uintptr_t)y;
+  const int vec = (S % 4 == 0) && ((al & 15) == 0);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, nchunk), dim3(256), 0, stream, dz, y, (const float*)nullptr, stats, part,
+                     N, C, S, nchunk, len, slope, vec, gmax);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, stream, part, nchunk, (double)N * (double)S, dgb, C,
+                     stats, training, (const unsigned*)gmax, ymax, ymax_slots, dyexps);
+  int pchunk; long plen;
+  chunking(S, C / 8, &pchunk, &plen);
+  hipLaunchKernelGGL(bn_bwd_apply_pack_kernel, dim3(pchunk, C / 8), dim3(256), 0, stream, dz, y, stats, dgb, dyexps,
+                     (char*)dyp, N, C, S, plen, slope, training);
   return dca_launch_status();
 }
 

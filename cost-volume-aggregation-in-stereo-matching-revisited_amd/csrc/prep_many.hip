@@ -11,7 +11,8 @@ struct PrepDesc {          // mirrored by ops.PrepackPlan (72 bytes)
   void* dst;
   int kind;                // 0: fp32 image (dca_conv3d_prep_weight), 1: bf16x3 image (dca_conv3d_x3_prep_weight),
                            // 2: bf16x3 fragments of a 1x1x1 conv (dca_conv1_x3_prep_weight)
-                           // 3: f16x2 image (dca_conv3d_x2_prep_weight): total f16 elements, then the 16-byte scale tail
+                           // (the f16x2 images of dca_conv3d_x2_prep_weight depend on the operand's per-channel exponents and
+                           // are packed per launch: not part of a plan)
   int A, Bn, Apad, Bpad, K, src_ab, flip, Btotal, b_off, NCH, pad_;
   long total;              // elements of dst
 };
@@ -25,31 +26,8 @@ __device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l)
 }
 
 
-// stage 1 of the kind-3 entries: {2^ew, 2^-ew, max |w|, 0} behind the packed image (x2_weight_scale_kernel)
-__global__ __launch_bounds__(1024) void prep_many_scale_kernel(const PrepDesc* __restrict__ table) {
-  const PrepDesc d = table[blockIdx.x];
-  if (d.kind != 3) return;
-  const long count = (long)d.A * d.Bn * 27;
-  float m = 0.f;
-  for (long i = threadIdx.x; i < count; i += 1024) m = fmaxf(m, fabsf(d.src[i]));
-  m = wave_max(m);
-  __shared__ float red[16];
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
-    const int ew = x2_scale_exp(__float_as_uint(m));
-    float* tail = (float*)((unsigned short*)d.dst + d.total);
-    tail[0] = x2_pow2(ew);
-    tail[1] = x2_pow2(-ew);
-    tail[2] = m;
-    tail[3] = 0.f;
-  }
-}
-
 __global__ __launch_bounds__(256) void prep_many_kernel(const PrepDesc* __restrict__ table) {
   const PrepDesc d = table[blockIdx.y];
-  const float ws = d.kind == 3 ? dca_coherent_loadf((const float*)((const unsigned short*)d.dst + d.total)) : 1.f;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < d.total; idx += (long)gridDim.x * 256) {
     if (d.kind == 0) {
       const int ab = d.Apad * d.Bpad;
@@ -71,22 +49,6 @@ __global__ __launch_bounds__(256) void prep_many_kernel(const PrepDesc* __restri
       split3(v, h, m, l);
       const __bf16 o = term == 0 ? h : (term == 1 ? m : l);
       ((unsigned short*)d.dst)[idx] = __builtin_bit_cast(unsigned short, o);
-    } else if (d.kind == 3) {
-      const int j = idx & 7, lane = (idx >> 3) & 63;
-      long t = idx >> 9;
-      const int term = t % 2; t /= 2;
-      const int tap = t % 27; t /= 27;
-      const int chunk = t % d.NCH;
-      const int cblk = (int)(t / d.NCH);
-      const int bi = cblk * 32 + (lane & 31), ai = chunk * 16 + 8 * (lane >> 5) + j;
-      float v = 0.f;
-      if (ai < d.A && bi < d.Bn) {
-        const int st = d.flip ? 26 - tap : tap;
-        v = d.src_ab ? d.src[((long)ai * d.Bn + bi) * 27 + st] : d.src[((long)bi * d.A + ai) * 27 + st];
-      }
-      const float u = v * ws;
-      const _Float16 h = (_Float16)u, l = (_Float16)(u - (float)h);
-      ((unsigned short*)d.dst)[idx] = __builtin_bit_cast(unsigned short, term == 0 ? h : l);
     } else {
       const int j = idx & 7, lane = (idx >> 3) & 63;
       long t = idx >> 9;
@@ -113,11 +75,9 @@ __global__ __launch_bounds__(256) void prep_many_kernel(const PrepDesc* __restri
 // table: n device-resident 72-byte descriptors {src, dst, kind, A, Bn, Apad, Bpad, K, src_ab, flip, Btotal, b_off, NCH,
 // pad, total} (pointers 8 bytes, ints 4, total 8) with the argument meaning of dca_conv3d_prep_weight (kind 0) /
 // dca_conv3d_x3_prep_weight (kind 1: A, Bn, src_ab, flip, NCH = ceil(A/16), total = weight_bytes/2) /
-// dca_conv1_x3_prep_weight (kind 2: A, Bn, src_ab, Btotal, b_off, total = weight_bytes/2) /
-// dca_conv3d_x2_prep_weight (kind 3: fields of kind 1, total = (weight_bytes - 16)/2; two launches: scales, then images).
+// dca_conv1_x3_prep_weight (kind 2: A, Bn, src_ab, Btotal, b_off, total = weight_bytes/2).
 extern "C" int dca_conv3d_prep_many(const void* table, int n, hipStream_t stream) {
   DCA_REQUIRE(table && n > 0 && n <= 65535 && (((uintptr_t)table) & 7) == 0);
-  hipLaunchKernelGGL(prep_many_scale_kernel, dim3(n), dim3(1024), 0, stream, (const PrepDesc*)table);
   hipLaunchKernelGGL(prep_many_kernel, dim3(48, n), dim3(256), 0, stream, (const PrepDesc*)table);
   return dca_launch_status();
 }

@@ -33,7 +33,9 @@ class Multi_Aggregation(nn.Module):
     def forward(self, x, res_post=None):
         # conv1 (stride 2) and redir (1x1x1) read the same x: one autograd node, so their two gradients of x are summed in
         # the second backward-data launch instead of by a separate accumulation pass (ops.convbn3d_pair)
-        c1, skip = ops.convbn3d_pair(x, self.conv1[0][0], self.conv1[0][1], 0.0, self.redir[0], self.redir[1], 1.0)
+        # (c1 has one consumer, the 3x3x3 convolution conv2: packed px2 operand in training)
+        c1, skip = ops.convbn3d_pair(x, self.conv1[0][0], self.conv1[0][1], 0.0, self.redir[0], self.redir[1], 1.0,
+                                     pack_a=True)
         c2 = self.conv2(c1)
         # relu(conv3(c2) + redir(x)) [+ res_post, fused: the caller's `cost0 + augmented_cost`]
         return self.conv3(c2, slope=0.0, res_pre=skip, res_post=res_post)

@@ -73,7 +73,8 @@ class _Dres0(nn.Sequential):
                          nn.ReLU(inplace=True))
 
     def forward(self, x):
-        return self[2](self[0](x, slope=0.0), slope=0.0)
+        # the first layer's only consumer is the second convolution: packed px2 operand in training (ops.convbn3d)
+        return self[2](self[0](x, slope=0.0, pack_out=True), slope=0.0)
 
 
 class _Dres1(nn.Sequential):
@@ -86,7 +87,7 @@ class _Dres1(nn.Sequential):
     def forward(self, x):
         # the residual reads x through the first convolution's alias output: its gradient is added inside that convolution's
         # backward-data launch (ops._Conv3d.forward, `alias`)
-        h, xa = self[0](x, slope=0.0, alias=True)
+        h, xa = self[0](x, slope=0.0, alias=True, pack_out=True)
         return self[2](h, slope=1.0, res_post=xa)
 
 

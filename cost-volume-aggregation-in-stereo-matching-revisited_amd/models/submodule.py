@@ -56,9 +56,10 @@ class ConvBn3d(nn.Sequential):
                          nn.BatchNorm3d(out_channels))
         assert (kernel_size, pad) in ((3, 1), (1, 0)) and stride in (1, 2)
 
-    def forward(self, x, slope=1.0, res_pre=None, res_post=None, x2=None, alias=False):
-        """alias=True: returns (z, x') -- x' = x for the other consumers of x (ops._Conv3d.forward)"""
-        return ops.convbn3d(x, self[0], self[1], slope, res_pre, res_post, x2, alias)
+    def forward(self, x, slope=1.0, res_pre=None, res_post=None, x2=None, alias=False, pack_out=False):
+        """alias=True: returns (z, x') -- x' = x for the other consumers of x (ops._Conv3d.forward);
+        pack_out=True: the result feeds exactly one 3x3x3 stride-1 ConvBn3d (ops.convbn3d)"""
+        return ops.convbn3d(x, self[0], self[1], slope, res_pre, res_post, x2, alias, pack_out)
 
 
 class ConvBnReLU3d(nn.Sequential):

@@ -43,7 +43,10 @@ def _chk(rc: int, name: str):
         raise RuntimeError(f"{name} failed with hipError_t {rc}")
 
 
-def _req(t: torch.Tensor, name: str) -> torch.Tensor:
+def _req(t: torch.Tensor, name: str, packed_ok: bool = False) -> torch.Tensor:
+    if getattr(t, "_dca_px2", None) is not None and not packed_ok:
+        raise RuntimeError(f"{name}: got a tensor in the packed px2 operand format (only the f16x2 3x3x3 stride-1 convolution "
+                           "reads it; ask the producer for an fp32 result)")
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise RuntimeError(
             f"{name}: the DCANet hot path runs only as HIP kernels on a ROCm device (got "
@@ -298,31 +301,27 @@ BN_FUSE = os.environ.get("DCA_BN_FUSE", "1") != "0"        # BatchNorm batch sta
 _X3_MIN_WORKGROUPS = 1
 
 
-# ---- operand maxima for the f16x2 kernels -----------------------------------------------------------------------------
-# A "word" is a view of AMAX_SLOTS int32 (DCA_AMAX_SLOTS of include/dca_hip.h): the maximum over them is the bit pattern of
-# max |t| as an fp32 number.  Kernels that produce a convolution operand fill it (BatchNorm apply / backward, the f16x2
-# convolution's own epilogue); it rides on the tensor object as `_dca_amax = (word, t._version)` (an in-place change of t
-# invalidates it).  Tensors without one get a read pass (dca_amax_f32).  Words come from zero-filled pools and are used
-# once; a pool allocated outside a stream capture is never handed out inside one (a captured graph must zero its own words
-# on every replay).
-AMAX_STATS = {"tagged": 0, "computed": 0}
-AMAX_SLOTS = 8192
-_AMAX_POOL_WORDS = 64
+# ---- operand scales of the f16x2 kernels --------------------------------------------------------------------------------
+# Every CHANNEL of an operand is scaled by its own power of two (csrc/dca_common.h).  What travels with a tensor object:
+#   t._dca_cmax = (slots, nslots, version): per-channel maxima the kernel that WROTE t emitted (BatchNorm apply / backward,
+#                 the f16x2 convolution's fused epilogue): slots[c * CSLOTS + s], s < nslots.  No zero-initialisation.
+#   t._dca_exps = (exps, version): the per-channel scale exponents (C ints) once somebody derived them (the weight-packing
+#                 kernel of the first convolution over t does, on the way).
+#   t._dca_px2  = (exps,): t is NOT fp32 data but the packed px2 image of an fp32 tensor of t's shape (the two scaled f16
+#                 terms, [term][C/8][D][H][W][8]), written by a BatchNorm kernel for the f16x2 convolution that consumes it.
+# `version` = t._version at tagging time: an in-place change of t invalidates the tag.  Tensors without a tag get one read
+# pass (dca_cmax_f32).
+AMAX_STATS = {"tagged": 0, "computed": 0, "packed": 0}
+CSLOTS = 256                                               # DCA_AMAX_CSLOTS of include/dca_hip.h
 AMAX_EMIT = os.environ.get("DCA_AMAX_EMIT", "1") != "0"    # 0: no producer-side maxima, every operand gets its read pass (A/B)
+PACK = os.environ.get("DCA_PACK", "1") != "0"              # 0: no packed px2 operands, fp32 tensors everywhere (A/B)
 
 
-def _amax_word(device):
+def _cslots(C, device):
+    """uninitialised per-channel slot words for a tensor with C channels (None when producer-side maxima are switched off)"""
     if not AMAX_EMIT:
         return None
-    cap = torch.cuda.is_current_stream_capturing()
-    pool = getattr(_tls, "amax_pool", None)
-    if pool is None or pool[1] >= _AMAX_POOL_WORDS or pool[2] != cap or pool[0].device != device or \
-            pool[3] != torch.cuda.current_stream(device):
-        pool = _tls.amax_pool = [torch.zeros((_AMAX_POOL_WORDS * AMAX_SLOTS,), device=device, dtype=torch.int32), 0, cap,
-                                 torch.cuda.current_stream(device)]
-    i = pool[1]
-    pool[1] = i + 1
-    return pool[0][i * AMAX_SLOTS:(i + 1) * AMAX_SLOTS]
+    return torch.empty((C * CSLOTS,), device=device, dtype=torch.int32)
 
 
 def _ver(t):
@@ -331,22 +330,70 @@ def _ver(t):
     return None if t.is_inference() else t._version
 
 
-def _tag_amax(t, word):
-    t._dca_amax = (word, _ver(t))
+def _tag_cmax(t, slots, nslots):
+    if slots is not None:
+        t._dca_cmax = (slots, int(nslots), _ver(t))
     return t
 
 
-def _amax_of(t):
-    """the max-|.| word of tensor t: the producer's if t carries a valid one, else one read pass over t"""
-    tag = getattr(t, "_dca_amax", None)
-    if tag is not None and tag[1] == _ver(t) and tag[0].device == t.device:
+def _tag_px2(t, exps):
+    t._dca_px2 = (exps,)
+    return t
+
+
+def _is_packed(t):
+    return getattr(t, "_dca_px2", None) is not None
+
+
+def _slots_of(t):
+    """(slots, nslots) of the fp32 tensor t (N, C, ...): the producer's if t carries valid ones, else one read pass"""
+    tag = getattr(t, "_dca_cmax", None)
+    if tag is not None and tag[2] == _ver(t) and tag[0].device == t.device:
         AMAX_STATS["tagged"] += 1
-        return tag[0]
+        return tag[0], tag[1]
     AMAX_STATS["computed"] += 1
-    word = torch.empty((AMAX_SLOTS,), device=t.device, dtype=torch.int32)
-    _chk(_L().dca_amax_f32(_ptr(t), t.numel(), _ptr(word), _stream()), "dca_amax_f32")
-    _tag_amax(t, word)
-    return word
+    N, C = t.shape[0], t.shape[1]
+    S = t[0, 0].numel()
+    slots = torch.empty((C * CSLOTS,), device=t.device, dtype=torch.int32)
+    lib = _L()
+    _chk(lib.dca_cmax_f32(_ptr(t), N, C, S, _ptr(slots), _stream()), "dca_cmax_f32")
+    nslots = lib.dca_bn_num_chunks(C, S)
+    t._dca_cmax = (slots, nslots, _ver(t))
+    return slots, nslots
+
+
+def _exps_cached(t):
+    if _is_packed(t):
+        return t._dca_px2[0]
+    tag = getattr(t, "_dca_exps", None)
+    if tag is not None and tag[1] == _ver(t) and tag[0].device == t.device:
+        return tag[0]
+    return None
+
+
+def _exps_of(t):
+    """per-channel scale exponents (C ints on the device) of operand t: packed tensor -> its own; cached; else from the slots"""
+    ex = _exps_cached(t)
+    if ex is not None:
+        return ex
+    slots, nslots = _slots_of(t)
+    C = t.shape[1]
+    ex = torch.empty((C,), device=t.device, dtype=torch.int32)
+    _chk(_L().dca_cmax_exps(_ptr(slots), nslots, C, _ptr(ex), _stream()), "dca_cmax_exps")
+    t._dca_exps = (ex, _ver(t))
+    return ex
+
+
+def pack_x2(x):
+    """the packed px2 image of an fp32 tensor (N, C % 8 == 0, D, H, W) with exponents from its per-channel maxima (tests,
+    micro-benchmarks; in the network the BatchNorm kernels write this format themselves)"""
+    x = _req(x, "pack_x2")
+    N, C = x.shape[0], x.shape[1]
+    S = x[0, 0].numel()
+    ex = _exps_of(x)
+    xp = torch.empty_like(x)
+    _chk(_L().dca_bn_apply_pack(_ptr(x), None, _ptr(ex), _ptr(xp), N, C, S, 1.0, None, _stream()), "dca_bn_apply_pack")
+    return _tag_px2(xp, ex)
 
 
 def _x3_eligible(x, x2, ksize, stride, transposed, A, B):
@@ -413,21 +460,24 @@ def _out_dims(dims, ksize, stride, transposed):
 
 
 def _conv_sliced(x, x2, w_src, A, B, K, src_ab, flip, ksize, stride, transposed, scale=None, shift=None, slope=1.0,
-                 res_pre=None, res_post=None, want_stats=False, x_amax=None, emit_amax=False):
+                 res_pre=None, res_post=None, want_stats=False, emit_amax=False):
     """y = conv(x [, x2]) with A contraction channels and B output channels, as ceil(B / slice) launches that each
     write their channel slice of y (w_src is the PyTorch weight; src_ab / flip as in dca_conv3d_prep_weight).
     want_stats (no epilogue then): returns (y, part) where part holds the BatchNorm batch-statistics partials of y emitted
     by the convolution kernel itself (B * nchunk * 4 doubles, csrc/bn_fused_stats.h), or (y, None) when the kernel serving
     this shape has no such form."""
     y, part = _conv_sliced_impl(x, x2, w_src, A, B, K, src_ab, flip, ksize, stride, transposed, scale, shift, slope,
-                                res_pre, res_post, want_stats, x_amax, emit_amax)
+                                res_pre, res_post, want_stats, emit_amax)
     return (y, part) if want_stats else y
 
 
 def _conv_sliced_impl(x, x2, w_src, A, B, K, src_ab, flip, ksize, stride, transposed, scale, shift, slope, res_pre,
-                      res_post, want_stats, x_amax=None, emit_amax=False):
-    """x_amax: the max-|.| word of x if the caller has it (f16x2 kernels; looked up / computed otherwise); emit_amax: tag y
-    with its own max-|.| word where the kernel serving this shape can emit one (inference chains conv -> conv)"""
+                      res_post, want_stats, emit_amax=False):
+    """x may be a packed px2 operand (f16x2 kernels only); emit_amax: tag y with its per-channel maxima where the kernel
+    serving this shape can emit them (inference chains conv -> conv)"""
+    packed = _is_packed(x)
+    if packed and not (CONV_X2 and _x3_eligible(x, x2, ksize, stride, transposed, A, B)):
+        raise RuntimeError("conv3d: a packed px2 operand can only feed the f16x2 3x3x3 stride-1 convolution")
     N = x.shape[0]
     Di, Hi, Wi = x.shape[2:]
     Do, Ho, Wo = _out_dims((Di, Hi, Wi), ksize, stride, transposed)
@@ -436,26 +486,32 @@ def _conv_sliced_impl(x, x2, w_src, A, B, K, src_ab, flip, ksize, stride, transp
     width = _slice_width(ksize, stride, transposed, B)
     lib = _L()
     if CONV_X2 and _x3_eligible(x, x2, ksize, stride, transposed, A, B):
-        def build_x2():
-            w2 = torch.empty((lib.dca_conv3d_x2_weight_bytes(A, B) // 2,), device=x.device, dtype=torch.int16)
-            _chk(lib.dca_conv3d_x2_prep_weight(_ptr(w_src), _ptr(w2), A, B, int(src_ab), int(flip), _stream()),
-                 "dca_conv3d_x2_prep_weight")
-            return w2
-        wx = _memo(("x2prep", A, B, int(src_ab), int(flip)), (w_src,), build_x2,
-                   (3, A, B, 0, 0, 27, int(src_ab), int(flip), B, 0))
-        xam = x_amax if x_amax is not None else _amax_of(x)
+        # the weights are packed per launch: the image folds the operand's per-channel exponents in (dca_hip.h); the
+        # packing kernel derives them from the operand's slots on the way and leaves them on the tensor for later users
+        # (the weight gradient of this convolution, other convolutions over the same tensor)
+        wx = torch.empty((lib.dca_conv3d_x2_weight_bytes(A, B) // 2,), device=x.device, dtype=torch.int16)
+        xexps = _exps_cached(x)
+        if xexps is not None:
+            AMAX_STATS["packed" if packed else "tagged"] += 1
+            slots, nslots = None, 0
+        else:
+            slots, nslots = _slots_of(x)
+            xexps = torch.empty((A,), device=x.device, dtype=torch.int32)
+        _chk(lib.dca_conv3d_x2_prep_weight(_ptr(w_src), _ptr(wx), A, B, int(src_ab), int(flip), _ptr(slots), nslots,
+                                           _ptr(xexps), _stream()), "dca_conv3d_x2_prep_weight")
+        if slots is not None:
+            x._dca_exps = (xexps, _ver(x))
         if want_stats:
             nchunk = lib.dca_conv3d_x2_stats_chunks(N, B, Di, Hi, Wi)
             part = torch.empty((B * nchunk * 4,), device=x.device, dtype=torch.float64)
-            _chk(lib.dca_conv3d_x2_forward_stats(_ptr(x), _ptr(xam), _ptr(wx), _ptr(y), _ptr(part), N, A, B, Di, Hi, Wi,
-                                                 _stream()), "dca_conv3d_x2_forward_stats")
+            _chk(lib.dca_conv3d_x2_forward_stats(_ptr(x), int(packed), _ptr(xexps), _ptr(wx), _ptr(y), _ptr(part), N, A, B,
+                                                 Di, Hi, Wi, _stream()), "dca_conv3d_x2_forward_stats")
             return y, part
-        yam = _amax_word(x.device) if emit_amax else None
-        _chk(lib.dca_conv3d_x2_forward(_ptr(x), _ptr(xam), _ptr(wx), _ptr(y), _ptr(scale), _ptr(shift), _ptr(res_pre),
-                                       _ptr(res_post), float(slope), _ptr(yam), N, A, B, Di, Hi, Wi, _stream()),
-             "dca_conv3d_x2_forward")
-        if yam is not None:
-            _tag_amax(y, yam)
+        ycm = _cslots(B, x.device) if emit_amax else None
+        _chk(lib.dca_conv3d_x2_forward(_ptr(x), int(packed), _ptr(xexps), _ptr(wx), _ptr(y), _ptr(scale), _ptr(shift),
+                                       _ptr(res_pre), _ptr(res_post), float(slope), _ptr(ycm), N, A, B, Di, Hi, Wi,
+                                       _stream()), "dca_conv3d_x2_forward")
+        _tag_cmax(y, ycm, lib.dca_conv3d_x2_stats_chunks(N, B, Di, Hi, Wi))
         return y, None
     if _x3_eligible(x, x2, ksize, stride, transposed, A, B):
         def build_x3():
@@ -551,25 +607,28 @@ def _conv_forward_impl(x, x2, weight, stride, transposed, scale=None, shift=None
         src_ab = 0
     assert x.shape[1] + (x2.shape[1] if x2 is not None else 0) == Cin, "conv3d: channel mismatch"
     return _conv_sliced(x, x2, weight, Cin, Cout, K, src_ab, 0, ksize, stride, transposed, scale, shift, slope,
-                        res_pre, res_post, want_stats, None, emit_amax)
+                        res_pre, res_post, want_stats, emit_amax)
 
 
-def _wgrad(x, dy, dw_view_ptr_tensor, dst_offset, Cx, Cy, ksize, stride, s_cy, s_cx, x_amax=None, y_amax=None):
-    """dw[cy*s_cy + cx*s_cx + k] (+dst_offset floats) = sum dy[cy] * x[cx] (see dca_hip.h)."""
+def _wgrad(x, dy, dw_view_ptr_tensor, dst_offset, Cx, Cy, ksize, stride, s_cy, s_cx):
+    """dw[cy*s_cy + cx*s_cx + k] (+dst_offset floats) = sum dy[cy] * x[cx] (see dca_hip.h); x / dy may be packed px2
+    operands (3x3x3 stride 1 on the f16x2 kernel only)."""
     N = x.shape[0]
     Di, Hi, Wi = x.shape[2:]
     Do, Ho, Wo = dy.shape[2:]
     dst = _vp(dw_view_ptr_tensor.data_ptr() + 4 * dst_offset)
     lib = _L()
-    if (CONV_X2 and CONV_X3 and ksize == 3 and stride == 1 and Wi % 4 == 0 and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0
-            and max(Cx, Cy) * Di * Hi * Wi * 4 < 0x7ffffff0):
-        xam = x_amax if x_amax is not None else _amax_of(x)
-        yam = y_amax if y_amax is not None else _amax_of(dy)
+    xp, yp = _is_packed(x), _is_packed(dy)
+    if (CONV_X2 and CONV_X3 and ksize == 3 and stride == 1 and (xp or Wi % 4 == 0) and (yp or Wi % 4 == 0)
+            and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0 and max(Cx, Cy) * Di * Hi * Wi * 4 < 0x7ffffff0):
+        xex, yex = _exps_of(x), _exps_of(dy)
         nws = lib.dca_conv3d_wgrad_x2_workspace(N, Cx, Cy, Di, Hi, Wi)
         part = torch.empty((nws,), device=x.device, dtype=torch.float32)
-        _chk(lib.dca_conv3d_wgrad_x2(_ptr(x), _ptr(xam), _ptr(dy), _ptr(yam), _ptr(part), dst, N, Cx, Cy, Di, Hi, Wi,
-                                     s_cy, s_cx, _stream()), "dca_conv3d_wgrad_x2")
+        _chk(lib.dca_conv3d_wgrad_x2(_ptr(x), int(xp), _ptr(xex), _ptr(dy), int(yp), _ptr(yex), _ptr(part), dst, N, Cx, Cy,
+                                     Di, Hi, Wi, s_cy, s_cx, _stream()), "dca_conv3d_wgrad_x2")
         return
+    if xp or yp:
+        raise RuntimeError("weight gradient: a packed px2 operand can only feed the f16x2 3x3x3 stride-1 kernel")
     if (CONV_X3 and ksize == 3 and stride == 1 and Wi % 4 == 0 and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0
             and max(Cx, Cy) * Di * Hi * Wi * 4 < 0x7ffffff0):
         nws = lib.dca_conv3d_wgrad_x3_workspace(N, Cx, Cy, Di, Hi, Wi)
@@ -581,11 +640,10 @@ def _wgrad(x, dy, dw_view_ptr_tensor, dst_offset, Cx, Cy, ksize, stride, s_cy, s
             and (Do, Ho, Wo) == ((Di + 1) // 2, (Hi + 1) // 2, (Wi + 1) // 2)
             and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0 and max(Cx, Cy) * Di * Hi * Wi * 4 < 0x7ffffff0):
         # stride-2 convolution / transposed convolution: x = the fine tensor, dy = the coarse one (conv3d_wgrad_s2_f16x2.hip)
-        xam = x_amax if x_amax is not None else _amax_of(x)
-        yam = y_amax if y_amax is not None else _amax_of(dy)
+        xex, yex = _exps_of(x), _exps_of(dy)
         nws = lib.dca_conv3d_wgrad_s2_x2_workspace(N, Cx, Cy, Di, Hi, Wi)
         part = torch.empty((nws,), device=x.device, dtype=torch.float32)
-        _chk(lib.dca_conv3d_wgrad_s2_x2(_ptr(x), _ptr(xam), _ptr(dy), _ptr(yam), _ptr(part), dst, N, Cx, Cy, Di, Hi, Wi,
+        _chk(lib.dca_conv3d_wgrad_s2_x2(_ptr(x), _ptr(xex), _ptr(dy), _ptr(yex), _ptr(part), dst, N, Cx, Cy, Di, Hi, Wi,
                                         s_cy, s_cx, _stream()), "dca_conv3d_wgrad_s2_x2")
         return
     nws = lib.dca_conv3d_wgrad_workspace(N, Cx, Cy, Do, Ho, Wo, ksize, stride)
@@ -634,27 +692,30 @@ class _Conv3d(torch.autograd.Function):
     Optional second input x2 = implicit channel concat for the 1x1x1 `fuse` conv."""
 
     @staticmethod
-    def forward(ctx, x, x2, weight, stride, transposed, want_stats=False, alias=False):
+    def forward(ctx, x, x2, weight, stride, transposed, want_stats=False, alias=False, packed_dy=False):
         """want_stats: returns (y, part) -- part = the BatchNorm batch-statistics partials of y from the convolution
         kernel's own epilogue (not differentiable; csrc/bn_fused_stats.h), empty where the kernel serving this shape
         cannot produce them.
         alias (3x3x3 stride 1 only): one more output, x itself, for the OTHER consumers of x -- their summed gradient comes
         back as that output's gradient and is added inside this convolution's backward-data launch (epilogue `+ res_post`)
         instead of by autograd's separate accumulation pass."""
-        x, weight = _req(x, "conv3d"), _req(weight, "conv3d.weight")
+        x, weight = _req(x, "conv3d", packed_ok=True), _req(weight, "conv3d.weight")
         x2 = _opt(x2, "conv3d.x2")
+        if _is_packed(x) and alias:
+            raise RuntimeError("conv3d: alias output of a packed px2 operand")
         ctx.save_for_backward(x, x2, weight)
         ctx.meta = (stride, transposed)
         ctx.alias = bool(alias)
-        ctx.x_amax = None
+        ctx.x_px2 = getattr(x, "_dca_px2", None)    # save_for_backward keeps the tensor, not its Python attributes
+        ctx.packed_dy = bool(packed_dy)              # the gradient of y arrives as a packed px2 operand (_BnAct, pack_dy)
+        ctx.x_exps = None
         with torch.cuda.device_of(x):
-            if (CONV_X2 and x2 is None and not transposed and stride == 1 and weight.shape[2] == 3
-                    and _x3_eligible(x, None, 3, 1, False, weight.shape[1], weight.shape[0])):
-                ctx.x_amax = _amax_of(x)     # forward and weight gradient scale x by the same word
             if not want_stats:
                 y = _conv_forward_impl(x, x2, weight, stride, transposed)
+                ctx.x_exps = _exps_cached(x)         # forward and weight gradient scale x by the same exponents
                 return (y, x.view_as(x)) if alias else y
             y, part = _conv_forward_impl(x, x2, weight, stride, transposed, want_stats=True)
+            ctx.x_exps = _exps_cached(x)
         if part is None:
             part = torch.empty((0,), device=x.device, dtype=torch.float64)
         ctx.mark_non_differentiable(part)
@@ -663,9 +724,16 @@ class _Conv3d(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, *rest):
         x, x2, weight = ctx.saved_tensors
+        if ctx.x_px2 is not None:
+            x._dca_px2 = ctx.x_px2
+        elif ctx.x_exps is not None and _exps_cached(x) is None:
+            x._dca_exps = (ctx.x_exps, _ver(x))
         stride, transposed = ctx.meta
         g_alias = _opt(rest[-1], "conv3d.backward") if (ctx.alias and rest) else None
-        dy = _req(dy, "conv3d.backward")
+        if ctx.packed_dy and not _is_packed(dy):
+            raise RuntimeError("conv3d.backward: expected the packed px2 gradient of the BatchNorm behind this convolution "
+                               "(the tag was lost on the way through autograd)")
+        dy = _req(dy, "conv3d.backward", packed_ok=True)
         ksize = weight.shape[2]
         K = ksize ** 3
         gx = gx2 = gw = None
@@ -690,7 +758,7 @@ class _Conv3d(torch.autograd.Function):
                             raise RuntimeError("stride-2 conv backward needs even input dims")
                 if need_w:
                     gw = torch.empty_like(weight)
-                    _wgrad(x, dy, gw, 0, Cin, Cout, 3, stride, Cin * K, K, x_amax=ctx.x_amax)
+                    _wgrad(x, dy, gw, 0, Cin, Cout, 3, stride, Cin * K, K)
             else:
                 Cout, Cin = weight.shape[0], weight.shape[1]
                 w2 = weight.reshape(Cout, Cin)
@@ -710,7 +778,7 @@ class _Conv3d(torch.autograd.Function):
                         _wgrad(x2, dy, gw, C1, Cin - C1, Cout, 1, 1, Cin, 1)
         if g_alias is not None:      # alias on a path without the fused form
             gx = g_alias if gx is None else gx + g_alias
-        return gx, gx2, gw, None, None, None, None
+        return gx, gx2, gw, None, None, None, None, None
 
 
 class _ConvPair(torch.autograd.Function):
@@ -756,18 +824,19 @@ class _ConvPair(torch.autograd.Function):
 PAIR_FUSE = os.environ.get("DCA_PAIR_FUSE", "1") != "0"
 
 
-def convbn3d_pair(x, conv_a, bn_a, slope_a, conv_b, bn_b, slope_b):
+def convbn3d_pair(x, conv_a, bn_a, slope_a, conv_b, bn_b, slope_b, pack_a=False):
     """(act(BN_a(conv_a(x))), act(BN_b(conv_b(x)))) for conv_a = Conv3d(k3, s2, p1), conv_b = Conv3d(k1) over the SAME x;
-    training path: one autograd node for the two convolutions (`_ConvPair`), otherwise two `convbn3d` calls"""
+    training path: one autograd node for the two convolutions (`_ConvPair`), otherwise two `convbn3d` calls.
+    pack_a: the first result has one consumer, a 3x3x3 stride-1 convolution (see convbn3d, pack_out)"""
     inference = (not bn_a.training and not bn_b.training and not torch.is_grad_enabled())
     ok = (PAIR_FUSE and not inference and _lp_dtype() is None and conv_a.kernel_size[0] == 3 and conv_a.stride[0] == 2
           and conv_b.kernel_size[0] == 1 and conv_b.weight.shape[0] in (32, 64) and x.dtype == torch.float32
           and not isinstance(conv_a, torch.nn.ConvTranspose3d) and all(d % 2 == 0 for d in x.shape[2:]))
     if not ok:
-        return convbn3d(x, conv_a, bn_a, slope_a), convbn3d(x, conv_b, bn_b, slope_b)
+        return convbn3d(x, conv_a, bn_a, slope_a, pack_out=pack_a), convbn3d(x, conv_b, bn_b, slope_b)
     stats = bool(BN_FUSE and bn_a.training and bn_b.training)
     ya, pa, yb, pb = _ConvPair.apply(x, conv_a.weight, conv_b.weight, stats)
-    za = bn_act(ya, bn_a, slope_a, stats_part=pa if pa.numel() else None)
+    za = bn_act(ya, bn_a, slope_a, stats_part=pa if pa.numel() else None, pack_out=pack_a)
     zb = bn_act(yb, bn_b, slope_b, stats_part=pb if pb.numel() else None)
     return za, zb
 
@@ -785,15 +854,16 @@ def conv3d_fused_inference(x, weight, stride, transposed, scale, shift, slope, r
     with torch.cuda.device_of(x):
         return _conv_forward_impl(x, _opt(x2, "x2"), weight, int(stride), bool(transposed), _opt(scale, "scale"),
                                   _opt(shift, "shift"), slope, _opt(res_pre, "res_pre"), _opt(res_post, "res_post"),
-                                  emit_amax=CONV_X2)
+                                  emit_amax=CONV_X2 and AMAX_EMIT)
 
 
 # ------------------------------------------------------------------------------------------------
 # BatchNorm3d + activation + residual
 # ------------------------------------------------------------------------------------------------
-def bn_stats_vector(y, gamma, beta, running_mean, running_var, training, momentum, eps, part=None):
+def bn_stats_vector(y, gamma, beta, running_mean, running_var, training, momentum, eps, part=None, zexps=None):
     """[mean | invstd | scale | shift] (4*C floats); updates the running stats in place when training.
-    part: partial statistics the producing convolution already emitted (dca_*_forward_stats), or None."""
+    part: partial statistics the producing convolution already emitted (dca_*_forward_stats), or None.
+    zexps (training only): C ints that receive the scale exponents of z = act(BN(y)) for the packed px2 output."""
     N, C = y.shape[0], y.shape[1]
     S = y[0, 0].numel()
     stats = torch.empty((4 * C,), device=y.device, dtype=torch.float32)
@@ -802,17 +872,18 @@ def bn_stats_vector(y, gamma, beta, running_mean, running_var, training, momentu
         if part is not None:     # one self-centred partial {K, n, s, q} per (channel, workgroup) of the producing conv
             _chk(lib.dca_bn_finalize_centered(_ptr(part), part.numel() // (4 * C), _ptr(gamma), _ptr(beta),
                                               _ptr(running_mean), _ptr(running_var), float(momentum), float(eps),
-                                              _ptr(stats), C, _stream()), "dca_bn_finalize_centered")
+                                              _ptr(stats), _ptr(zexps), C, _stream()), "dca_bn_finalize_centered")
             return stats
         nchunk = lib.dca_bn_num_chunks(C, S)
         part = torch.empty((C * nchunk * 2 + C,), device=y.device, dtype=torch.float64)   # partial sums + C shifts
         _chk(lib.dca_bn_stats(_ptr(y), _ptr(part), N, C, S, _stream()), "dca_bn_stats")
         _chk(lib.dca_bn_finalize(_ptr(part), nchunk, float(N * S), _ptr(gamma), _ptr(beta), _ptr(running_mean),
-                                 _ptr(running_var), float(momentum), float(eps), 1, _ptr(stats), C, _stream()),
+                                 _ptr(running_var), float(momentum), float(eps), 1, _ptr(stats), _ptr(zexps), C, _stream()),
              "dca_bn_finalize")
     else:
+        assert zexps is None
         _chk(lib.dca_bn_finalize(None, 0, float(N * S), _ptr(gamma), _ptr(beta), _ptr(running_mean),
-                                 _ptr(running_var), float(momentum), float(eps), 0, _ptr(stats), C, _stream()),
+                                 _ptr(running_var), float(momentum), float(eps), 0, _ptr(stats), None, C, _stream()),
              "dca_bn_finalize")
     return stats
 
@@ -824,7 +895,7 @@ def bn_eval_affine(bn):
     def build():
         stats = torch.empty((4 * C,), device=bn.running_mean.device, dtype=torch.float32)
         _chk(_L().dca_bn_finalize(None, 0, 1.0, _ptr(bn.weight), _ptr(bn.bias), _ptr(bn.running_mean),
-                                  _ptr(bn.running_var), 0.1, float(bn.eps), 0, _ptr(stats), C, _stream()),
+                                  _ptr(bn.running_var), 0.1, float(bn.eps), 0, _ptr(stats), None, C, _stream()),
              "dca_bn_finalize")
         return stats
     src = tuple(t for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var) if t is not None)
@@ -832,29 +903,44 @@ def bn_eval_affine(bn):
 
 
 class _BnAct(torch.autograd.Function):
-    """z = act(BN(y) + res_pre) + res_post with nn.BatchNorm3d semantics."""
+    """z = act(BN(y) + res_pre) + res_post with nn.BatchNorm3d semantics.
+    pack_z:  z is written in the packed px2 operand format (for ONE consumer: an f16x2 convolution) instead of fp32.
+    pack_dy: backward writes the gradient of y in the packed px2 format (y's producer is an f16x2 convolution: its
+             backward-data and weight-gradient kernels are the only readers)."""
 
     @staticmethod
     def forward(ctx, y, gamma, beta, running_mean, running_var, training, momentum, eps, slope, res_pre, res_post,
-                part=None, amax=None):
-        """amax: zero word that receives max |z| (see _amax_word); the caller tags z with it"""
+                part=None, zmax=None, pack_z=False, pack_dy=False):
+        """zmax: per-channel slot words that receive max |z| (see _cslots); the caller tags z with them"""
         y = _req(y, "batch_norm")
         res_pre, res_post = _opt(res_pre, "res_pre"), _opt(res_post, "res_post")
         N, C = y.shape[0], y.shape[1]
         S = y[0, 0].numel()
+        lib = _L()
+        pack_z = bool(pack_z and training and res_pre is None and res_post is None and C % 8 == 0)
+        pack_dy = bool(pack_dy and res_pre is None and C % 8 == 0)
         with torch.cuda.device_of(y):
-            stats = bn_stats_vector(y, gamma, beta, running_mean, running_var, training, momentum, eps, part)
+            zexps = torch.empty((C,), device=y.device, dtype=torch.int32) if pack_z else None
+            stats = bn_stats_vector(y, gamma, beta, running_mean, running_var, training, momentum, eps, part, zexps)
+            ymax = torch.empty((C * CSLOTS,), device=y.device, dtype=torch.int32) if pack_dy else None
             z = torch.empty_like(y)
-            _chk(_L().dca_bn_apply(_ptr(y), _ptr(stats), _ptr(res_pre), _ptr(res_post), _ptr(z), N, C, S, float(slope),
-                                   _ptr(amax), _stream()), "dca_bn_apply")
-        ctx.save_for_backward(y, stats, res_pre if slope != 1.0 else None)
-        ctx.meta = (training, slope, res_pre is not None, res_post is not None)
+            if pack_z:
+                _chk(lib.dca_bn_apply_pack(_ptr(y), _ptr(stats), _ptr(zexps), _ptr(z), N, C, S, float(slope), _ptr(ymax),
+                                           _stream()), "dca_bn_apply_pack")
+                ymax_slots = lib.dca_bn_pack_chunks(C, S)
+            else:
+                _chk(lib.dca_bn_apply(_ptr(y), _ptr(stats), _ptr(res_pre), _ptr(res_post), _ptr(z), N, C, S, float(slope),
+                                      _ptr(zmax), _ptr(ymax), _stream()), "dca_bn_apply")
+                ymax_slots = lib.dca_bn_num_chunks(C, S)
+        ctx.save_for_backward(y, stats, res_pre if slope != 1.0 else None, ymax)
+        ctx.meta = (training, slope, res_pre is not None, res_post is not None, pack_dy, ymax_slots)
+        _tls.last_zexps = zexps       # picked up by bn_act right after apply() (same thread, synchronous)
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        y, stats, res_pre = ctx.saved_tensors
-        training, slope, has_pre, has_post = ctx.meta
+        y, stats, res_pre, ymax = ctx.saved_tensors
+        training, slope, has_pre, has_post, pack_dy, ymax_slots = ctx.meta
         dz = _req(dz, "batch_norm.backward")
         N, C = y.shape[0], y.shape[1]
         S = y[0, 0].numel()
@@ -864,19 +950,27 @@ class _BnAct(torch.autograd.Function):
             part = torch.empty((C * nchunk * 2,), device=y.device, dtype=torch.float64)
             dgb = torch.empty((4 * C,), device=y.device, dtype=torch.float32)
             dy = torch.empty_like(y)
-            want_g = has_pre and slope != 1.0 and ctx.needs_input_grad[9]
-            g_out = torch.empty_like(y) if want_g else None
-            am = _amax_word(y.device) if CONV_X2 else None      # max |dy| for the convolution's backward kernels
-            _chk(lib.dca_bn_backward(_ptr(dz), _ptr(y), _ptr(res_pre), _ptr(stats), _ptr(part), _ptr(dgb), _ptr(dy),
-                                     _ptr(g_out), N, C, S, float(slope), int(training), _ptr(am), _stream()),
-                 "dca_bn_backward")
-            if am is not None:
-                _tag_amax(dy, am)
+            g_out = None
+            if pack_dy:
+                dyexps = torch.empty((C,), device=y.device, dtype=torch.int32)
+                gmax = torch.empty((C * CSLOTS,), device=y.device, dtype=torch.int32)
+                _chk(lib.dca_bn_backward_pack(_ptr(dz), _ptr(y), _ptr(stats), _ptr(part), _ptr(dgb), _ptr(dy), _ptr(dyexps),
+                                              _ptr(gmax), _ptr(ymax), ymax_slots if ymax is not None else 0, N, C, S,
+                                              float(slope), int(training), _stream()), "dca_bn_backward_pack")
+                _tag_px2(dy, dyexps)
+            else:
+                want_g = has_pre and slope != 1.0 and ctx.needs_input_grad[9]
+                g_out = torch.empty_like(y) if want_g else None
+                dm = _cslots(C, y.device) if CONV_X2 else None     # per-channel max |dy| for the convolution's backward kernels
+                _chk(lib.dca_bn_backward(_ptr(dz), _ptr(y), _ptr(res_pre), _ptr(stats), _ptr(part), _ptr(dgb), _ptr(dy),
+                                         _ptr(g_out), N, C, S, float(slope), int(training), _ptr(dm), _stream()),
+                     "dca_bn_backward")
+                _tag_cmax(dy, dm, nchunk)
         g_pre = None
         if has_pre and ctx.needs_input_grad[9]:
-            g_pre = g_out if want_g else dz
+            g_pre = g_out if g_out is not None else dz
         g_post = dz if (has_post and ctx.needs_input_grad[10]) else None
-        return dy, dgb[:C], dgb[C:2 * C], None, None, None, None, None, None, g_pre, g_post, None, None
+        return dy, dgb[:C], dgb[C:2 * C], None, None, None, None, None, None, g_pre, g_post, None, None, None, None
 
 
 _tls = threading.local()
@@ -1012,18 +1106,26 @@ class batched_bn_counters:
         return False
 
 
-def bn_act(y, bn, slope=1.0, res_pre=None, res_post=None, stats_part=None):
+def bn_act(y, bn, slope=1.0, res_pre=None, res_post=None, stats_part=None, pack_out=False, pack_dy=False):
     """Applies the nn.BatchNorm3d module `bn` (parameters/buffers only; its forward is never called).
-    stats_part: batch-statistics partial sums of y from the producing convolution (`_Conv3d` with want_stats), if it made them."""
+    stats_part: batch-statistics partial sums of y from the producing convolution (`_Conv3d` with want_stats), if it made them.
+    pack_out: the result has ONE consumer, an f16x2 3x3x3 stride-1 convolution: write it in the packed px2 operand format
+    (training BatchNorm without residuals only; plain fp32 otherwise).  pack_dy: see _BnAct."""
     momentum = 0.1 if bn.momentum is None else bn.momentum
     training = bn.training or bn.running_mean is None
     if _lp_dtype() is not None:
         raise RuntimeError("ops.reduced_precision is inference only: call the model in eval mode under torch.no_grad()")
-    am = _amax_word(y.device) if CONV_X2 else None          # max |z|: the next convolution's operand scale
+    C = y.shape[1]
+    pack_z = bool(pack_out and PACK and CONV_X2 and training and res_pre is None and res_post is None and C % 8 == 0
+                  and torch.is_grad_enabled())
+    pack_dy = bool(pack_dy and PACK and CONV_X2 and res_pre is None and C % 8 == 0)
+    zm = _cslots(C, y.device) if (CONV_X2 and not pack_z) else None     # per-channel max |z|: the next convolution's operand scales
     z = _BnAct.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, float(slope),
-                     res_pre, res_post, stats_part if training else None, am)
-    if am is not None:
-        _tag_amax(z, am)
+                     res_pre, res_post, stats_part if training else None, zm, pack_z, pack_dy)
+    if pack_z:
+        _tag_px2(z, _tls.last_zexps)
+    elif zm is not None:
+        _tag_cmax(z, zm, _L().dca_bn_num_chunks(C, y[0, 0].numel()))
     if bn.training and bn.num_batches_tracked is not None:
         pending = getattr(_tls, "pending", None)
         if pending is not None:
@@ -1059,12 +1161,26 @@ def _lp_dtype():
     return getattr(_tls, "lp", None)
 
 
-def convbn3d(x, conv, bn, slope=1.0, res_pre=None, res_post=None, x2=None, alias=False):
+def _pack_dy_ok(x, x2, conv, transposed, stride, res_pre):
+    """may the gradient of this convolution's output travel as a packed px2 operand?  (its only readers are then the f16x2
+    backward-data and weight-gradient kernels of this very convolution)"""
+    if not (PACK and CONV_X2 and x2 is None and not transposed and stride == 1 and conv.kernel_size[0] == 3 and res_pre is None):
+        return False
+    Cout, Cin = conv.weight.shape[0], conv.weight.shape[1]
+    if Cout % 8 or Cout < 8 or not _x3_eligible(x, None, 3, 1, False, Cin, Cout):
+        return False
+    return _is_packed(x) or (x.shape[-1] % 4 == 0 and x.data_ptr() % 16 == 0)
+
+
+def convbn3d(x, conv, bn, slope=1.0, res_pre=None, res_post=None, x2=None, alias=False, pack_out=False):
     """`convbn_3d` (models/submodule.py:121-124) + activation + residual adds, on the HIP kernels.
 
     conv: nn.Conv3d / nn.ConvTranspose3d (bias=False), bn: nn.BatchNorm3d -- used as parameter holders.
     Inference (eval BN, no grad): one fused launch (BN folded into the conv epilogue).  Otherwise conv ->
-    batch statistics -> apply, each with a HIP backward."""
+    batch statistics -> apply, each with a HIP backward.
+    pack_out: the caller promises that the result has ONE consumer and that it is a 3x3x3 stride-1 convolution through this
+    function: in training the BatchNorm apply pass then writes the packed px2 operand format (csrc/dca_common.h) instead
+    of fp32 (never with residuals; silently fp32 wherever the packed form does not apply)."""
     transposed = isinstance(conv, torch.nn.ConvTranspose3d)
     stride = conv.stride[0]
     if alias:
@@ -1075,9 +1191,11 @@ def convbn3d(x, conv, bn, slope=1.0, res_pre=None, res_post=None, x2=None, alias
         if not fuse:
             return convbn3d(x, conv, bn, slope, res_pre, res_post, x2), x
         stats = bool(BN_FUSE and bn.training)
-        out = _Conv3d.apply(x, None, conv.weight, 1, False, stats, True)
+        pdy = _pack_dy_ok(x, None, conv, False, 1, res_pre)
+        out = _Conv3d.apply(x, None, conv.weight, 1, False, stats, True, pdy)
         y, part, xa = (out[0], out[1], out[2]) if stats else (out[0], None, out[1])
-        z = bn_act(y, bn, slope, res_pre, res_post, part if (part is not None and part.numel()) else None)
+        z = bn_act(y, bn, slope, res_pre, res_post, part if (part is not None and part.numel()) else None,
+                   pack_out=pack_out, pack_dy=pdy)
         return z, xa
     if not bn.training and not torch.is_grad_enabled():
         lp = _lp_dtype()
@@ -1096,8 +1214,9 @@ def convbn3d(x, conv, bn, slope=1.0, res_pre=None, res_post=None, x2=None, alias
     if BN_FUSE and bn.training and conv.weight.shape[0 if not transposed else 1] > 1 and _lp_dtype() is None:
         # the convolution kernel emits the batch statistics of its own output where it has such a form (the bf16x3 family):
         # no separate pass over y
-        y, part = _Conv3d.apply(x, x2, conv.weight, int(stride), bool(transposed), True)
-        return bn_act(y, bn, slope, res_pre, res_post, part if part.numel() else None)
+        pdy = _pack_dy_ok(x, x2, conv, transposed, stride, res_pre)
+        y, part = _Conv3d.apply(x, x2, conv.weight, int(stride), bool(transposed), True, False, pdy)
+        return bn_act(y, bn, slope, res_pre, res_post, part if part.numel() else None, pack_out=pack_out, pack_dy=pdy)
     y = conv3d(x, conv.weight, stride, transposed, x2)
     return bn_act(y, bn, slope, res_pre, res_post)
 

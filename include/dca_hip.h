@@ -23,7 +23,7 @@ extern "C" {
 
 /* Bumped whenever an argument list below changes; the ctypes loader (_lib.py) refuses a library built from another
  * version of this header. */
-#define DCA_ABI_VERSION 12
+#define DCA_ABI_VERSION 13
 int dca_abi_version(void);
 
 /* storage types of the reduced-precision inference path (0 = fp32) */
@@ -176,7 +176,8 @@ int dca_deconv3d_x3_forward_stats(const float* x, const void* wx, float* y, doub
 /* [mean | invstd | scale | shift] (4*C floats) from those partials, with the running-statistics update of training-mode
  * nn.BatchNorm3d (momentum, unbiased variance); running_mean / running_var may both be null. */
 int dca_bn_finalize_centered(const double* part, int nchunk, const float* gamma, const float* beta, float* running_mean,
-                             float* running_var, float momentum, float eps, float* stats, int C, hipStream_t stream);
+                             float* running_var, float momentum, float eps, float* stats, int* zexps, int C,
+                             hipStream_t stream);
 
 /* Weight gradient of the 3x3x3 / stride-1 / pad-1 convolution on the bf16 matrix pipe with the same exact three-way
  * bf16 split (conv3d_wgrad_bf16x3.hip); replaces dca_conv3d_wgrad for ksize 3, stride 1 (autograd's dW of the nn.Conv3d
@@ -188,32 +189,40 @@ int dca_conv3d_wgrad_x3(const float* x, const float* dy, float* part, float* dw,
                         int W, long s_cy, long s_cx, hipStream_t stream);
 
 /* "f16x2" split-precision 3x3x3 / stride-1 / pad-1 convolution and weight gradient (conv3d_f16x2.hip,
- * conv3d_wgrad_f16x2.hip) -- the kernels the models run: each fp32 operand is scaled by a power of two taken from its
- * tensor's max |.| (scaled maximum in [2^14, 2^15): inside the f16 range whatever the tensor's magnitude), split into two
- * f16 terms (|x - h - l| <= 2^-22 |x|) and the three partial products >= 2^-11 run on the f16 matrix pipe with fp32
- * accumulation; the result is scaled back in the epilogue.  Half the matrix-pipe cycles of the bf16x3 kernels at the
- * same measured error against fp64.  Same operators as dca_conv3d_x3_forward / dca_conv3d_wgrad_x3
- * (models/submodule.py:121-124, models/augment/cva.py:13-55) and, with src_ab = 1 / flip = 1, their backward-data.
- *   Operand maxima: a tensor's max |.| is passed as DCA_AMAX_SLOTS (8192) device words; every workgroup (or wave) of the
- *       producing kernel stores the bit pattern of its own maximum (a non-negative fp32 number) into a slot of its own, the
- *       consumer takes the unsigned maximum over all words.  No atomics (bitwise reproducible; and atomicMax-filled words
- *       were read wrongly inside hipGraph replays).  Producers need ZERO-initialised words.
- *   dca_amax_f32: words <- max |x[0..n)| (a 32 KB zero fill and one read pass); the BatchNorm kernels fill the same words
- *       for the tensors they write (dca_bn_apply / dca_bn_backward, `amax`).
- *   dca_conv3d_x2_weight_bytes / dca_conv3d_x2_prep_weight: packed image (fragments, then {2^ew, 2^-ew, max |w|, 0});
- *       argument meaning of dca_conv3d_x3_prep_weight.
- *   dca_conv3d_x2_forward[_stats]: contracts of dca_conv3d_x3_forward[_stats]; x_amax = the operand's words; y_amax (may
- *       be null) = zero-initialised words that receive max |y| for the next convolution.
- *   dca_conv3d_wgrad_x2: contract of dca_conv3d_wgrad_x3; x_amax / y_amax = the words of x and dy. */
-#define DCA_AMAX_SLOTS 8192
-int dca_amax_f32(const float* x, long n, unsigned* words, hipStream_t stream);
+ * conv3d_wgrad_f16x2.hip, conv3d_wgrad_s2_f16x2.hip) -- the kernels the models run: every CHANNEL of an fp32 operand is
+ * scaled by its own power of two 2^exps[c] (scaled maximum in [2^14, 2^15): inside the f16 range whatever the channel's
+ * magnitude and whatever the other channels'), split into two f16 terms (|x - h - l| <= 2^-22 |x|) and the three partial
+ * products >= 2^-11 run on the f16 matrix pipe with fp32 accumulation; the result is scaled back exactly (v_ldexp_f32).
+ * Half the matrix-pipe cycles of the bf16x3 kernels at the same measured error against fp64, per output channel
+ * (tests/test_gpu_parity.py::test_f16x2_per_channel_scales).  Same operators as dca_conv3d_x3_forward /
+ * dca_conv3d_wgrad_x3 (models/submodule.py:121-124, models/augment/cva.py:13-55) and, with src_ab = 1 / flip = 1, their
+ * backward-data.
+ *   Per-channel maxima ("slots"): slots[c * DCA_AMAX_CSLOTS + s], s < nslots = the bit patterns of partial maxima of |x| over
+ *       channel c, one slot per producing workgroup (plain stores, one writer per slot, nothing to zero-initialise; the
+ *       consumer takes the unsigned maximum).  Filled by dca_bn_apply (zmax), dca_bn_backward (dmax),
+ *       dca_conv3d_x2_forward (y_cmax) for the tensors they write, or by dca_cmax_f32 (a read pass; nslots =
+ *       dca_bn_num_chunks(C, S)).  dca_cmax_exps: exps[c] from the slots.
+ *   Packed operand "px2": the fp32 tensor (N,C,D,H,W), C % 8 == 0, as its two scaled f16 terms, per sample
+ *       [term 2][C/8][D][H][W][8] f16 (4 bytes per element, like fp32), written by dca_bn_apply_pack / dca_bn_backward_pack
+ *       (or dca_bn_apply_pack with stats = null: plain packing) together with the exponents it was scaled by.  Consumers:
+ *       dca_conv3d_x2_forward[_stats] (packed = 1) and dca_conv3d_wgrad_x2 (x_packed / dy_packed).
+ *   dca_conv3d_x2_prep_weight: packs w for ONE launch over an operand with exponents xexps (it folds 2^-xexps[k] into
+ *       the weight rows and gives every output channel its own scale): x_slots == null -> xexps is an input;
+ *       else xexps is derived from the slots and written (A ints) for later users of the same operand.
+ *   dca_conv3d_x2_forward[_stats]: contracts of dca_conv3d_x3_forward[_stats]; y_cmax (may be null; forces the fused
+ *       epilogue variant) = per-channel slots that receive max |y|, nslots = dca_conv3d_x2_stats_chunks(...).
+ *   dca_conv3d_wgrad_x2 / _s2_x2: contracts of dca_conv3d_wgrad_x3 / the stride-2 form below; exps of both operands. */
+#define DCA_AMAX_CSLOTS 256
+int dca_cmax_f32(const float* x, int N, int C, long S, unsigned* slots, hipStream_t stream);
+int dca_cmax_exps(const unsigned* slots, int nslots, int C, int* exps, hipStream_t stream);
 long dca_conv3d_x2_weight_bytes(int Cin, int Cout);
-int dca_conv3d_x2_prep_weight(const float* w, void* wx, int A, int B, int src_ab, int flip, hipStream_t stream);
-int dca_conv3d_x2_forward(const float* x, const unsigned* x_amax, const void* wx, float* y, const float* scale,
-                          const float* shift, const float* res_pre, const float* res_post, float slope, unsigned* y_amax,
+int dca_conv3d_x2_prep_weight(const float* w, void* wx, int A, int B, int src_ab, int flip, const unsigned* x_slots,
+                              int nslots, int* xexps, hipStream_t stream);
+int dca_conv3d_x2_forward(const void* x, int packed, const int* xexps, const void* wx, float* y, const float* scale,
+                          const float* shift, const float* res_pre, const float* res_post, float slope, unsigned* y_cmax,
                           int N, int Cin, int Cout, int D, int H, int W, hipStream_t stream);
 long dca_conv3d_x2_stats_chunks(int N, int Cout, int D, int H, int W);
-int dca_conv3d_x2_forward_stats(const float* x, const unsigned* x_amax, const void* wx, float* y, double* stat_part,
+int dca_conv3d_x2_forward_stats(const void* x, int packed, const int* xexps, const void* wx, float* y, double* stat_part,
                                 int N, int Cin, int Cout, int D, int H, int W, hipStream_t stream);
 /* dca_conv3d_wgrad_s2_x2: the same arithmetic for the weight gradient of the STRIDE-2 convolution `cost_agg.conv1` and of
  * the transposed convolution `cost_agg.conv3` (models/augment/cva.py:16-29; conv3d_wgrad_s2_f16x2.hip):
@@ -221,11 +230,12 @@ int dca_conv3d_x2_forward_stats(const float* x, const unsigned* x_amax, const vo
  * (N,Cy,(D+1)/2,(H+1)/2,(W+1)/2); for the transposed convolution f = dy, c = x.  Requires W % 4 == 0, (W+1)/2 % 4 == 0 and
  * 16-byte aligned tensors (hipErrorInvalidValue otherwise: callers use dca_conv3d_wgrad). */
 long dca_conv3d_wgrad_s2_x2_workspace(int N, int Cx, int Cy, int D, int H, int W);
-int dca_conv3d_wgrad_s2_x2(const float* f, const unsigned* f_amax, const float* c, const unsigned* c_amax, float* part,
+int dca_conv3d_wgrad_s2_x2(const float* f, const int* f_exps, const float* c, const int* c_exps, float* part,
                            float* dw, int N, int Cx, int Cy, int D, int H, int W, long s_cy, long s_cx, hipStream_t stream);
 long dca_conv3d_wgrad_x2_workspace(int N, int Cx, int Cy, int D, int H, int W);
-int dca_conv3d_wgrad_x2(const float* x, const unsigned* x_amax, const float* dy, const unsigned* y_amax, float* part,
-                        float* dw, int N, int Cx, int Cy, int D, int H, int W, long s_cy, long s_cx, hipStream_t stream);
+int dca_conv3d_wgrad_x2(const void* x, int x_packed, const int* xexps, const void* dy, int dy_packed, const int* yexps,
+                        float* part, float* dw, int N, int Cx, int Cy, int D, int H, int W, long s_cy, long s_cx,
+                        hipStream_t stream);
 
 /* Single-output-channel 3x3x3 convolution (the logit heads: nn.Conv3d(32, 1, 3, padding=1, bias=False),
  * models/gwcnet_dca_g.py:154-168 `classif*.2`, models/augment/cva.py:51-53 `classify.2`).  w is the PyTorch weight
@@ -248,19 +258,32 @@ int dca_conv3d_c1_bwd_data(const float* dy, const float* w, float* dx, int N, in
  * dca_bn_apply:    z = act(scale*y + shift + res_pre) + res_post.
  * dca_bn_backward: given dz -> dy (grad of the conv output), dgb = [dgamma | dbeta | ...] (4*C floats),
  *                  optional g_out = grad w.r.t. res_pre (= dz masked by the activation).
- * amax (dca_bn_apply: of z, dca_bn_backward: of dy; may be null): DCA_AMAX_SLOTS ZERO-initialised device words that receive
- *                  max |.| of the tensor written (see "f16x2" above) -- the operand maximum the f16x2 convolution
- *                  kernels scale by. */
+ * zmax / dmax (dca_bn_apply: of z, dca_bn_backward: of dy; may be null): per-channel slots (see "f16x2" above; nslots =
+ *                  dca_bn_num_chunks(C, S)) that receive max |.| of the tensor written; ymax (dca_bn_apply[_pack]; may be
+ *                  null): slots that receive max |y - mean| per channel (it bounds |xhat| for the backward pass' scale).
+ * zexps (dca_bn_finalize[_centered]; may be null, training only): per-channel scale exponents for z = act(BN(y)) from the
+ *                  bound |z| <= |gamma| sqrt(count) + |beta| -- known before z is written, so that
+ * dca_bn_apply_pack writes z directly in the packed px2 format (no residuals; stats = null: plain packing of y with zexps);
+ *                  nslots of its ymax = dca_bn_pack_chunks(C, S).
+ * dca_bn_backward_pack: dca_bn_backward (no res_pre / g_out) writing dy in the packed px2 format; dyexps (C ints, out) =
+ *                  the exponents it was scaled by (bound from max |g|, this launch's reduce pass, and max |xhat| = invstd *
+ *                  ymax); gmax = scratch of C * DCA_AMAX_CSLOTS words. */
 int dca_bn_num_chunks(int C, long S);
+int dca_bn_pack_chunks(int C, long S);
 int dca_bn_stats(const float* x, double* part, int N, int C, long S, hipStream_t stream);
 int dca_bn_finalize(const double* part, int nchunk, double count, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float momentum, float eps, int training, float* stats,
-                    int C, hipStream_t stream);
+                    int* zexps, int C, hipStream_t stream);
 int dca_bn_apply(const float* y, const float* stats, const float* res_pre, const float* res_post, float* z, int N,
-                 int C, long S, float slope, unsigned* amax, hipStream_t stream);
+                 int C, long S, float slope, unsigned* zmax, unsigned* ymax, hipStream_t stream);
+int dca_bn_apply_pack(const float* y, const float* stats, const int* zexps, void* zp, int N, int C, long S, float slope,
+                      unsigned* ymax, hipStream_t stream);
 int dca_bn_backward(const float* dz, const float* y, const float* res_pre, const float* stats, double* part,
                     float* dgb, float* dy, float* g_out, int N, int C, long S, float slope, int training,
-                    unsigned* amax, hipStream_t stream);
+                    unsigned* dmax, hipStream_t stream);
+int dca_bn_backward_pack(const float* dz, const float* y, const float* stats, double* part, float* dgb, void* dyp,
+                         int* dyexps, unsigned* gmax, const unsigned* ymax, int ymax_slots, int N, int C, long S,
+                         float slope, int training, hipStream_t stream);
 
 /* ---- AvgPool3d((3,3,3), stride 2, padding 1) -- models/augment/cva.py:39 ---------------------------- */
 int dca_avgpool3d_fwd(const float* x, float* y, long NC, int Di, int Hi, int Wi, hipStream_t stream);

@@ -42,6 +42,26 @@ def gpu(t, grad=False):
     return t.detach().to(DEV).requires_grad_(grad)
 
 
+def rel_l2(a, b):
+    a, b = torch.as_tensor(a).detach().cpu().double(), torch.as_tensor(b).detach().cpu().double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+class _GradProbe(torch.autograd.Function):
+    """identity whose backward records the gradient OBJECT it receives (with its Python attributes: the way
+    ops._Conv3d.backward receives the gradient ops._BnAct.backward produced)"""
+    seen = {}
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        _GradProbe.seen["g"] = g
+        return g
+
+
 def cpu_leaf(t):
     return t.detach().clone().requires_grad_()
 
@@ -507,9 +527,10 @@ def test_conv3d_bf16x3_fused_epilogue(fam, monkeypatch):
     y = ops._conv_sliced(x.to(DEV), None, w.to(DEV), cin, cout, 27, 0, 0, 3, 1, False, sc.to(DEV), sh.to(DEV), 0.1,
                          rp.to(DEV), rq.to(DEV), emit_amax=True)
     close(y, ref, 1e-5, "fused")
-    if fam == "f16x2":   # the epilogue's own max |y| word, for the next convolution
-        word = y._dca_amax[0].view(torch.float32).max().item()
-        assert word == y.abs().max().item(), (word, y.abs().max().item())
+    if fam == "f16x2":   # the epilogue's own per-channel max |y| slots, for the next convolution
+        slots, nslots, _ = y._dca_cmax
+        got = slots.view(torch.float32).view(cout, ops.CSLOTS)[:, :nslots].amax(1)
+        assert torch.equal(got, y.abs().amax((0, 2, 3, 4))), (got, y.abs().amax((0, 2, 3, 4)))
 
 
 @pytest.mark.parametrize("mag", [1e-12, 1.0, 3e4], ids=["1e-12", "1", "3e4"])
@@ -535,12 +556,13 @@ def test_conv3d_f16x2_any_magnitude(mag, monkeypatch):
 
 
 def test_f16x2_producer_maxima_equal_read_pass(monkeypatch):
-    """the operand maxima the BatchNorm kernels / the convolution epilogue emit are exactly the tensor's max |.|, so a
+    """the per-channel operand maxima the BatchNorm kernels / the convolution epilogue emit are exactly the channels' max |.|, so a
     training step (conv -> BN -> ReLU -> conv, backward) gives BITWISE the same result with producer-side maxima as with
     a read pass per operand (DCA_AMAX_EMIT=0)"""
     _, ops = _mods()
     import torch.nn as nn
     _family(monkeypatch, ops, "f16x2")
+    monkeypatch.setattr(ops, "PACK", False)     # packed operands are scaled by bounds, not by the exact maxima: own tests below
     c1 = nn.Conv3d(32, 32, 3, 1, 1, bias=False).to(DEV); b1 = nn.BatchNorm3d(32).to(DEV)
     c2 = nn.Conv3d(32, 32, 3, 1, 1, bias=False).to(DEV); b2 = nn.BatchNorm3d(32).to(DEV)
     x = seeded_tensor("x2p.x", (2, 32, 6, 10, 24)).to(DEV)
@@ -563,6 +585,209 @@ def test_f16x2_producer_maxima_equal_read_pass(monkeypatch):
     for a, b in zip(res[True], res[False]):
         assert torch.equal(a, b)
     assert torch.isfinite(res[True][1]).all() and res[True][1].abs().max() > 0
+
+
+# ------------------------------------------------------------------------------------- f16x2: per-channel scales, packed operands
+def _chan_err(got, ref):
+    """per output channel: max |got - ref| relative to that channel's max |ref|"""
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    dims = [d for d in range(ref.dim()) if d != 1]
+    return (got - ref).abs().amax(dims) / ref.abs().amax(dims).clamp_min(1e-300)
+
+
+@pytest.mark.parametrize("spread", [1e2, 1e4, 1e6, 1e8], ids=lambda s: f"{s:.0e}")
+def test_f16x2_per_channel_scales(spread, monkeypatch):
+    """the reference's fp32 convolution (models/submodule.py:121-124) is accurate per element whatever the
+    channels' scales.  Operand channels spread over `spread` (1e2 ... 1e8) and a BLOCK-DIAGONAL weight, so that output
+    channel o reads input channel o alone: the error of every output channel, relative to THAT channel's maximum, must not
+    depend on the spread -- forward, backward-data (per-channel spread of dy) and both weight gradients (stride 1 and
+    stride 2; per-channel spreads of x and dy; dW[o][i] relative to its own (o, i) block).  Gate: within 3x of the fp32-MFMA
+    kernel's per-channel error (an f16 pair carries 22 bits against fp32's 24: with only 27 products per output the operand
+    representation, not the accumulation, sets the error) and below 1e-6 absolutely."""
+    _, ops = _mods()
+    C, dims = 32, (4, 8, 16)
+    g = torch.Generator().manual_seed(11)
+    sc = torch.tensor(spread) ** (-torch.arange(C, dtype=torch.float64) / (C - 1))       # 1 ... 1/spread
+    sc = sc[torch.randperm(C, generator=g)].float()
+    x = torch.randn(2, C, *dims, generator=g) * sc.view(1, C, 1, 1, 1)
+    wd = torch.zeros(C, C, 3, 3, 3)
+    wd[torch.arange(C), torch.arange(C)] = torch.randn(C, 3, 3, 3, generator=g)
+    sd = sc[torch.randperm(C, generator=g)]
+    dy = torch.randn(2, C, *dims, generator=g) * sd.view(1, C, 1, 1, 1)
+    xr, wr = x.double().requires_grad_(), wd.double().requires_grad_()
+    yr = F.conv3d(xr, wr, None, 1, 1)
+    gxr, gwr = torch.autograd.grad((yr * dy.double()).sum(), [xr, wr])
+
+    def run(fam):
+        _family(monkeypatch, ops, fam)
+        xg, wg = gpu(x, True), gpu(wd, True)
+        y = ops.conv3d(xg, wg, 1, False)
+        gx, gw = torch.autograd.grad((y * dy.to(DEV)).sum(), [xg, wg])
+        return y, gx, gw
+    got, base = run("f16x2"), run("fp32mfma")
+    for name, a, b, ref in (("fwd", got[0], base[0], yr), ("dx", got[1], base[1], gxr)):
+        e2, e32 = _chan_err(a, ref), _chan_err(b, ref)
+        assert (e2 <= 3.0 * e32 + 1e-7).all() and e2.max() <= 1e-6, (name, spread, e2.max().item(), e32.max().item())
+    # weight gradient: the (o, o) diagonal blocks carry the products of channel o of dy and channel o of x
+    diag = lambda t: t.detach().cpu().double()[torch.arange(C), torch.arange(C)]          # (C, 3, 3, 3)
+    e2 = (diag(got[2]) - diag(gwr)).abs().amax((1, 2, 3)) / diag(gwr).abs().amax((1, 2, 3))
+    e32 = (diag(base[2]) - diag(gwr)).abs().amax((1, 2, 3)) / diag(gwr).abs().amax((1, 2, 3))
+    assert (e2 <= 3.0 * e32 + 2e-7).all() and e2.max() <= 1e-6, ("dw", spread, e2.max().item(), e32.max().item())
+    # stride-2 weight gradient (conv3d_wgrad_s2_f16x2.hip): coarse dy (2, C, 2, 4, 8)
+    dyc = torch.randn(2, C, 2, 4, 8, generator=g) * sd.view(1, C, 1, 1, 1)
+    ref2 = torch.nn.grad.conv3d_weight(x.double(), (C, C, 3, 3, 3), dyc.double(), stride=2, padding=1)
+    res = {}
+    for on in (True, False):
+        _family(monkeypatch, ops, "f16x2")
+        monkeypatch.setattr(ops, "WGRAD_S2_X2", on)
+        gw2 = torch.empty(C, C, 3, 3, 3, device=DEV)
+        ops._wgrad(x.to(DEV), dyc.to(DEV), gw2, 0, C, C, 3, 2, C * 27, 27)
+        # every (o, i) block relative to its own maximum: the blocks differ by up to spread^2
+        blk = lambda t: t.detach().cpu().double().reshape(C, C, 27)
+        res[on] = ((blk(gw2) - blk(ref2)).abs().amax(2) / blk(ref2).abs().amax(2)).max().item()
+    assert res[True] <= 3.0 * res[False] + 2e-7 and res[True] <= 1e-6, (spread, res)
+
+
+def test_f16x2_tiny_gradients(monkeypatch):
+    """max |dy| = 1e-20 (round 2 clamped the scale at 2^60 and lost the low term below ~1e-14): backward-data and weight
+    gradient keep their relative accuracy"""
+    _, ops = _mods()
+    _family(monkeypatch, ops, "f16x2")
+    x = seeded_tensor("x2t.x", (1, 32, 4, 8, 16)); w = seeded_tensor("x2t.w", (32, 32, 3, 3, 3)) * 0.05
+    dy = seeded_tensor("x2t.g", (1, 32, 4, 8, 16))
+    dy = dy / dy.abs().max() * 1e-20
+    xr, wr = x.double().requires_grad_(), w.double().requires_grad_()
+    gxr, gwr = torch.autograd.grad((F.conv3d(xr, wr, None, 1, 1) * dy.double()).sum(), [xr, wr])
+    xg, wg = gpu(x, True), gpu(w, True)
+    gx, gw = torch.autograd.grad((ops.conv3d(xg, wg, 1, False) * dy.to(DEV)).sum(), [xg, wg])
+    for got, ref, name in ((gx, gxr, "dx"), (gw, gwr, "dw")):
+        err = (got.detach().cpu().double() - ref).abs().max().item()
+        assert err <= 2e-6 * ref.abs().max().item(), (name, err, ref.abs().max().item())
+
+
+def _unpack_px2(tp, exps):
+    """fp64 value of a packed px2 tensor (CPU): (h + l) 2^-exps[c]"""
+    N, C = tp.shape[0], tp.shape[1]
+    S = tp[0, 0].numel()
+    raw = tp.detach().cpu().contiguous().view(torch.int16).view(N, 2, C // 8, S, 8).view(torch.float16).double()
+    v = (raw[:, 0] + raw[:, 1]).permute(0, 1, 3, 2).reshape(N, C, S)                 # (N, C/8, S, 8) -> (N, C, S)
+    v = v * torch.exp2(-exps.detach().cpu().double()).view(1, C, 1)
+    return v.view(tp.shape)
+
+
+def test_px2_pack_roundtrip_and_packed_operands_are_bitwise(monkeypatch):
+    """the packed px2 operand format (csrc/dca_common.h): (1) unpacking gives the tensor back to 2^-22 of each channel's
+    scale; (2) a packed operand holds exactly the two terms the fp32 staging path computes, so the convolution (forward,
+    statistics form, residual-add form) and the weight gradient give BITWISE the same result from packed and fp32 operands,
+    in all four operand combinations"""
+    _, ops = _mods()
+    _family(monkeypatch, ops, "f16x2")
+    for (N, cin, cout, dims) in ((2, 32, 32, (5, 9, 20)), (1, 40, 64, (3, 7, 18)), (1, 64, 64, (4, 6, 36))):
+        x = (seeded_tensor("px2.x", (N, cin) + dims) * torch.exp2(torch.arange(cin).float() % 7).view(1, cin, 1, 1, 1)).to(DEV)
+        dy = (seeded_tensor("px2.g", (N, cout) + dims) * 1e-3).to(DEV)
+        w = (seeded_tensor("px2.w", (cout, cin, 3, 3, 3)) * 0.05).to(DEV)
+        xp, dyp = ops.pack_x2(x), ops.pack_x2(dy)
+        back = _unpack_px2(xp, xp._dca_px2[0])
+        bound = x.abs().amax((0, 2, 3, 4)).cpu().double().view(1, cin, 1, 1, 1)
+        assert ((back - x.cpu().double()).abs() <= 2.0 ** -22 * x.cpu().double().abs() + 2.0 ** -39 * bound).all()
+        y0 = ops._conv_sliced(x, None, w, cin, cout, 27, 0, 0, 3, 1, False)
+        y1 = ops._conv_sliced(xp, None, w, cin, cout, 27, 0, 0, 3, 1, False)
+        assert torch.equal(y0, y1), "forward"
+        (s0, p0), (s1, p1) = (ops._conv_sliced(t, None, w, cin, cout, 27, 0, 0, 3, 1, False, want_stats=True) for t in (x, xp))
+        assert torch.equal(s0, s1) and torch.equal(p0, p1) and torch.equal(s0, y0), "statistics form"
+        r = seeded_tensor("px2.r", (N, cin) + dims).to(DEV)
+        b0 = ops._conv_sliced(dy, None, w, cout, cin, 27, 1, 1, 3, 1, False, res_post=r)       # backward-data + alias gradient
+        b1 = ops._conv_sliced(dyp, None, w, cout, cin, 27, 1, 1, 3, 1, False, res_post=r)
+        assert torch.equal(b0, b1), "backward-data"
+        gws = []
+        for a in (x, xp):
+            for b in (dy, dyp):
+                gw = torch.empty(cout, cin, 3, 3, 3, device=DEV)
+                ops._wgrad(a, b, gw, 0, cin, cout, 3, 1, cin * 27, 27)
+                gws.append(gw)
+        assert all(torch.equal(gws[0], t) for t in gws[1:]), "weight gradient"
+        ref = torch.nn.grad.conv3d_weight(x.cpu().double(), (cout, cin, 3, 3, 3), dy.cpu().double(), padding=1)
+        close_l2(gws[3], ref.float(), 2e-6, "dw (packed, packed)")
+
+
+@pytest.mark.parametrize("slope", [0.0, 0.1, 1.0])
+def test_bn_pack_kernels_match_fp32_kernels(slope, monkeypatch):
+    """dca_bn_apply_pack / dca_bn_backward_pack write what dca_bn_apply / dca_bn_backward write, in the packed px2 format:
+    unpacked they agree to 2^-21 of the channel's maximum; the exponents come from bounds (|z| <= |gamma| sqrt(n) + |beta|;
+    |dy| from max |g| and max |xhat|), which must hold: no element overflows the f16 range (all finite, scaled |.| < 2^15)"""
+    _, ops = _mods()
+    import torch.nn as nn
+    _family(monkeypatch, ops, "f16x2")
+    N, C, dims = 2, 32, (4, 6, 20)
+    bn = nn.BatchNorm3d(C).to(DEV)
+    with torch.no_grad():
+        bn.weight.copy_(seeded_tensor("bnp.g", (C,)).abs() + 0.5); bn.bias.copy_(seeded_tensor("bnp.b", (C,)))
+    y = (seeded_tensor("bnp.y", (N, C) + dims) * 3 + 1).to(DEV)
+    dz = (seeded_tensor("bnp.dz", (N, C) + dims) * torch.exp2(-(torch.arange(C) % 9).float()).view(1, C, 1, 1, 1)).to(DEV)
+    outs = {}
+    for pack in (False, True):
+        bn.reset_running_stats()
+        yy = y.clone().requires_grad_()
+        z = ops.bn_act(_GradProbe.apply(yy), bn, slope, pack_out=pack, pack_dy=pack)
+        zz = z
+        if pack:
+            assert ops._is_packed(z)
+            zz = _unpack_px2(z, z._dca_px2[0]).float().to(DEV)
+            raw = z.detach().cpu().view(torch.int16).view(torch.float16)
+            assert torch.isfinite(raw).all() and raw.abs().max() < 2.0 ** 15
+        # backward through the node (dz is an ordinary fp32 gradient in both cases)
+        z.backward(dz)
+        g = _GradProbe.seen.pop("g")
+        if pack:
+            tag = getattr(g, "_dca_px2", None)
+            assert tag is not None, "packed gradient expected"
+            raw = g.detach().cpu().view(torch.int16).view(torch.float16)
+            assert torch.isfinite(raw).all() and raw.abs().max() < 2.0 ** 15
+            g = _unpack_px2(g, tag[0]).float().to(DEV)
+        outs[pack] = (zz.detach(), g.detach(), bn.weight.grad.clone(), bn.bias.grad.clone())
+        bn.weight.grad = bn.bias.grad = None
+    for name, a, b in zip(("z", "dy", "dgamma", "dbeta"), outs[True], outs[False]):
+        if a.dim() == 5:
+            e = _chan_err(a, b)
+            assert e.max() <= 2.0 ** -21, (name, slope, e.max().item())
+        else:
+            assert torch.equal(a, b), name
+
+
+def test_packed_training_chain_matches_fp32_chain(monkeypatch):
+    """conv -> BN -> ReLU -> conv -> BN (+ residual) trained one step with packed px2 operands between the layers (z1 and
+    both gradients dy1, dy2 never exist as fp32 tensors) against the same chain with fp32 operands everywhere and against
+    PyTorch in fp64: same accuracy class"""
+    _, ops = _mods()
+    import torch.nn as nn
+    _family(monkeypatch, ops, "f16x2")
+    c1 = nn.Conv3d(40, 32, 3, 1, 1, bias=False).to(DEV); b1 = nn.BatchNorm3d(32).to(DEV)
+    c2 = nn.Conv3d(32, 32, 3, 1, 1, bias=False).to(DEV); b2 = nn.BatchNorm3d(32).to(DEV)
+    x = seeded_tensor("pch.x", (2, 40, 6, 10, 24)).to(DEV)
+    r = seeded_tensor("pch.r", (2, 32, 6, 10, 24)).to(DEV)
+    gz = seeded_tensor("pch.g", (2, 32, 6, 10, 24)).to(DEV) * 1e-3
+    res = {}
+    for pack in (True, False):
+        monkeypatch.setattr(ops, "PACK", pack)
+        for b in (b1, b2):
+            b.reset_running_stats()
+        before = dict(ops.AMAX_STATS)
+        xx = x.clone().requires_grad_()
+        z = ops.convbn3d(ops.convbn3d(xx, c1, b1, 0.0, pack_out=True), c2, b2, 1.0, res_post=r)
+        g = torch.autograd.grad((z * gz).sum(), [xx, c1.weight, c2.weight, b1.weight, b1.bias])
+        res[pack] = [z.detach()] + [t.detach() for t in g]
+        if pack:
+            assert ops.AMAX_STATS["packed"] - before["packed"] >= 3     # conv2 forward, both backward-data launches
+    # fp64 reference
+    m = nn.Sequential(nn.Conv3d(40, 32, 3, 1, 1, bias=False), nn.BatchNorm3d(32), nn.ReLU(), nn.Conv3d(32, 32, 3, 1, 1, bias=False),
+                      nn.BatchNorm3d(32)).double()
+    m[0].weight.data.copy_(c1.weight.detach().cpu()); m[3].weight.data.copy_(c2.weight.detach().cpu())
+    xr = x.cpu().double().requires_grad_()
+    zr = m(xr) + r.cpu().double()
+    gr = torch.autograd.grad((zr * gz.cpu().double()).sum(), [xr, m[0].weight, m[3].weight, m[1].weight, m[1].bias])
+    for i, (a, b, ref) in enumerate(zip(res[True], res[False], [zr] + list(gr))):
+        ea, eb = rel_l2(a, ref), rel_l2(b, ref)
+        assert ea <= 2.0 * eb + 2e-6, (i, ea, eb)
 
 
 def test_frozen_weights_cache_is_exact_and_scoped():
