@@ -579,7 +579,7 @@ def test_f16x2_producer_maxima_equal_read_pass(monkeypatch):
         res[emit] = [z.detach()] + [t.detach() for t in g]
         used = {k: ops.AMAX_STATS[k] - before[k] for k in before}
         if emit:
-            assert used["tagged"] >= 4, used      # z1 (forward + weight gradient), dy2, dy1 came with their tensors
+            assert used["tagged"] >= 3 and used["computed"] <= 1, used   # z1, dy2, dy1 came with their tensors; x needs its pass
         else:
             assert used["computed"] >= 4, used    # x, z1, dy2, dy1: one read pass each
     for a, b in zip(res[True], res[False]):
