@@ -706,6 +706,7 @@ class _Conv3d(torch.autograd.Function):
         ctx.save_for_backward(x, x2, weight)
         ctx.meta = (stride, transposed)
         ctx.alias = bool(alias)
+        ctx.set_materialize_grads(False)             # an unused output's gradient arrives as None, not as a tensor of zeros
         ctx.x_px2 = getattr(x, "_dca_px2", None)    # save_for_backward keeps the tensor, not its Python attributes
         ctx.packed_dy = bool(packed_dy)              # the gradient of y arrives as a packed px2 operand (_BnAct, pack_dy)
         ctx.x_exps = None
@@ -730,6 +731,8 @@ class _Conv3d(torch.autograd.Function):
             x._dca_exps = (ctx.x_exps, _ver(x))
         stride, transposed = ctx.meta
         g_alias = _opt(rest[-1], "conv3d.backward") if (ctx.alias and rest) else None
+        if dy is None:       # y was not used: nothing flows through the convolution, only past it (alias)
+            return g_alias, None, None, None, None, None, None, None
         if ctx.packed_dy and not _is_packed(dy):
             raise RuntimeError("conv3d.backward: expected the packed px2 gradient of the BatchNorm behind this convolution "
                                "(the tag was lost on the way through autograd)")

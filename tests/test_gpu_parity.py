@@ -702,12 +702,14 @@ def test_px2_pack_roundtrip_and_packed_operands_are_bitwise(monkeypatch):
         gws = []
         for a in (x, xp):
             for b in (dy, dyp):
+                if dims[2] % 4 and not (ops._is_packed(a) and ops._is_packed(b)):
+                    continue          # an fp32 operand of the f16x2 weight-gradient kernel needs W % 4 == 0
                 gw = torch.empty(cout, cin, 3, 3, 3, device=DEV)
                 ops._wgrad(a, b, gw, 0, cin, cout, 3, 1, cin * 27, 27)
                 gws.append(gw)
         assert all(torch.equal(gws[0], t) for t in gws[1:]), "weight gradient"
         ref = torch.nn.grad.conv3d_weight(x.cpu().double(), (cout, cin, 3, 3, 3), dy.cpu().double(), padding=1)
-        close_l2(gws[3], ref.float(), 2e-6, "dw (packed, packed)")
+        close_l2(gws[-1], ref.float(), 2e-6, "dw (packed, packed)")
 
 
 @pytest.mark.parametrize("slope", [0.0, 0.1, 1.0])
@@ -790,11 +792,14 @@ def test_packed_training_chain_matches_fp32_chain(monkeypatch):
         assert ea <= 2.0 * eb + 2e-6, (i, ea, eb)
 
 
-def test_frozen_weights_cache_is_exact_and_scoped():
+@pytest.mark.parametrize("fam", ["f16x2", "bf16x3"])
+def test_frozen_weights_cache_is_exact_and_scoped(fam, monkeypatch):
     """ops.frozen_weights(): cached weight re-layouts / BN folds give bit-identical results, are reused inside the
-    context, and are dropped (weights may change again) outside it"""
+    context, and are dropped (weights may change again) outside it.  (The f16x2 weight images fold the operand's per-channel
+    exponents in and are packed per launch: only the BatchNorm fold is cached for that family.)"""
     _, ops = _mods()
     import torch.nn as nn
+    _family(monkeypatch, ops, fam)
     conv = nn.Conv3d(32, 32, 3, 1, 1, bias=False).to(DEV); bn = nn.BatchNorm3d(32).to(DEV).eval()
     with torch.no_grad():
         conv.weight.copy_(seeded_tensor("fw.w", conv.weight.shape).to(DEV) * 0.05)
@@ -805,7 +810,7 @@ def test_frozen_weights_cache_is_exact_and_scoped():
             y1 = ops.convbn3d(x, conv, bn, 0.0)
             n_cached = len(ops._tls.frozen)
             y2 = ops.convbn3d(x, conv, bn, 0.0)
-            assert len(ops._tls.frozen) == n_cached and n_cached >= 2     # weight image + BN fold, reused
+            assert len(ops._tls.frozen) == n_cached and n_cached >= (2 if fam == "bf16x3" else 1)   # weight image + BN fold, reused
         assert torch.equal(y0, y1) and torch.equal(y0, y2)
         assert getattr(ops._tls, "frozen", None) is None
         conv.weight.mul_(2.0)                                              # outside the context: picked up at once
@@ -1322,7 +1327,8 @@ def test_prepack_plan_matches_per_call_packing():
     with plan.recording():
         run()
     plan.finalize()
-    assert plan.n >= 6                                  # forward + backward-data layouts of the 3x3x3 convs
+    assert plan.n >= 3                                  # forward + backward-data layouts of the stride-2 / transposed convs
+                                                        # (the f16x2 images are packed per launch: not planned)
     for out, desc, tensors in plan.entries.values():    # refresh() reproduces the recorded images bit for bit
         keep = out.clone(); out.zero_()
         plan.refresh()
