@@ -593,15 +593,16 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
 //      cblk*32 + r][k = input channel chunk*16 + 8h + j] of the tap = w 2^(f_o - xexps[k]), split into term 0/1 = h/l;
 //      zero padded;  f_o goes behind the images (ofo[cblk*32 + r]).
 // Source indexing as dca_conv3d_prep_weight: src_ab ? src[a][b][27] : src[b][a][27]; flip reverses the tap order.
-__global__ __launch_bounds__(1024) void x2_prep_weight_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
-                                                               int A, int Bn, int NCH, int src_ab, int flip,
-                                                               const unsigned* __restrict__ slots, int nslots,
-                                                               int* __restrict__ xexps, int xexps_given, int* __restrict__ ofo) {
+constexpr int PREP_ROWS = 4;       // output channels per workgroup of the packing kernel (8 workgroups per block of 32)
+__global__ __launch_bounds__(512) void x2_prep_weight_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
+                                                              int A, int Bn, int NCH, int src_ab, int flip,
+                                                              const unsigned* __restrict__ slots, int nslots,
+                                                              int* __restrict__ xexps, int xexps_given, int* __restrict__ ofo) {
   __shared__ int xe[MAX_CIN];
-  __shared__ int rowmax[32];
-  const int tid = threadIdx.x, cblk = blockIdx.x;
-  if (slots && !xexps_given) {     // 16 threads per channel, 64 channels per round
-    for (int c0 = 0; c0 < A; c0 += 64) {
+  __shared__ int rowmax[PREP_ROWS][2];
+  const int tid = threadIdx.x, cblk = blockIdx.x / (32 / PREP_ROWS), r0 = (blockIdx.x % (32 / PREP_ROWS)) * PREP_ROWS;
+  if (slots && !xexps_given) {     // 16 threads per channel, 32 channels per round; every workgroup derives its own copy
+    for (int c0 = 0; c0 < A; c0 += 32) {
       const int c = c0 + (tid >> 4), l = tid & 15;
       unsigned v = 0;
       if (c < A)
@@ -611,20 +612,19 @@ __global__ __launch_bounds__(1024) void x2_prep_weight_kernel(const float* __res
       if (c < A && l == 0) {
         const int e = x2_scale_exp(v);
         xe[c] = e;
-        if (cblk == 0) xexps[c] = e;
+        if (blockIdx.x == 0) xexps[c] = e;
       }
     }
   } else {
-    for (int c = tid; c < A; c += 1024) xe[c] = dca_coherent_loadi(xexps + c);
+    for (int c = tid; c < A; c += 512) xe[c] = dca_coherent_loadi(xexps + c);
   }
-  if (tid < 32) rowmax[tid] = -100000;
   __syncthreads();
-  // row r = tid >> 5 (32 threads per output channel): exponent of the largest |w 2^-xexps[k]| of the row
+  // row r = tid >> 7 (128 threads = 2 waves per output channel): exponent of the largest |w 2^-xexps[k]| of the row
   {
-    const int r = tid >> 5, l = tid & 31, bi = cblk * 32 + r;
+    const int r = tid >> 7, l = tid & 127, bi = cblk * 32 + r0 + r;
     int m = -100000;
     if (bi < Bn) {
-      for (int i = l; i < A * 27; i += 32) {
+      for (int i = l; i < A * 27; i += 128) {
         const int ai = i / 27, tap = i - ai * 27;
         const float v = src_ab ? src[((long)ai * Bn + bi) * 27 + tap] : src[((long)bi * A + ai) * 27 + tap];
         const int be = (int)((__float_as_uint(v) >> 23) & 255);      // biased exponent; 0: zero / denormal -> ignored
@@ -633,33 +633,40 @@ __global__ __launch_bounds__(1024) void x2_prep_weight_kernel(const float* __res
       }
     }
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1) { const int u = __shfl_xor(m, o, 64); m = m > u ? m : u; }
-    if (l == 0) {
-      const int fo = m <= -100000 ? 0 : 14 - m;
-      rowmax[r] = fo;
-      ofo[cblk * 32 + r] = fo;
-    }
+    for (int o = 32; o > 0; o >>= 1) { const int u = __shfl_xor(m, o, 64); m = m > u ? m : u; }
+    if ((l & 63) == 0) rowmax[r][l >> 6] = m;
   }
   __syncthreads();
-  const long per_blk = (long)NCH * 27 * NT * 512;     // f16 elements of one output-channel block's images
-  unsigned short* out = dst + cblk * per_blk;
-  for (long idx = tid; idx < per_blk; idx += 1024) {
-    const int j = idx & 7, lane = (idx >> 3) & 63;
-    long t = idx >> 9;
-    const int term = t % NT; t /= NT;
-    const int tap = t % 27;
-    const int chunk = (int)(t / 27);
-    const int r = lane & 31, bi = cblk * 32 + r, ai = chunk * 16 + 8 * (lane >> 5) + j;
-    float v = 0.f;
-    int e = 0;
-    if (ai < A && bi < Bn) {
-      const int st = flip ? 26 - tap : tap;
-      v = src_ab ? src[((long)ai * Bn + bi) * 27 + st] : src[((long)bi * A + ai) * 27 + st];
-      e = rowmax[r] - xe[ai];
+  if (tid < PREP_ROWS) {
+    const int m = rowmax[tid][0] > rowmax[tid][1] ? rowmax[tid][0] : rowmax[tid][1];
+    const int fo = m <= -100000 ? 0 : 14 - m;
+    rowmax[tid][0] = fo;
+    ofo[cblk * 32 + r0 + tid] = fo;
+  }
+  __syncthreads();
+  // items (chunk, tap, k half, row): the 8 input channels of one lane's fragment, both terms: two 16-byte stores
+  const int nitems = NCH * 27 * 2 * PREP_ROWS;
+  unsigned short* out = dst + (long)cblk * NCH * 27 * NT * 512;
+  for (int it = tid; it < nitems; it += 512) {
+    const int r = it % PREP_ROWS, hf = (it / PREP_ROWS) & 1, t = it / (2 * PREP_ROWS), tap = t % 27, chunk = t / 27;
+    const int bi = cblk * 32 + r0 + r, st = flip ? 26 - tap : tap, fo = rowmax[r][0];
+    f16x8 hv, lv;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ai = chunk * 16 + 8 * hf + j;
+      float v = 0.f;
+      int e = 0;
+      if (ai < A && bi < Bn) {
+        v = src_ab ? src[((long)ai * Bn + bi) * 27 + st] : src[((long)bi * A + ai) * 27 + st];
+        e = fo - xe[ai];
+      }
+      _Float16 h, l;
+      split2(v, e, h, l);
+      hv[j] = h; lv[j] = l;
     }
-    _Float16 h, l;
-    split2(v, e, h, l);
-    out[idx] = __builtin_bit_cast(unsigned short, term == 0 ? h : l);
+    const long o = ((long)(chunk * 27 + tap) * NT) * 512 + (hf * 32 + r0 + r) * 8;      // f16 elements; term stride 512
+    *(f16x8*)(out + o) = hv;
+    *(f16x8*)(out + o + 512) = lv;
   }
 }
 
@@ -681,8 +688,8 @@ extern "C" int dca_conv3d_x2_prep_weight(const float* w, void* wx, int A, int B,
   DCA_REQUIRE(x_slots == nullptr || (nslots > 0 && nslots <= DCA_AMAX_CSLOTS));
   const int NCH = (A + 15) / 16, cblks = (B + 31) / 32;
   int* ofo = (int*)((char*)wx + (long)cblks * NCH * 27 * NT * 1024);
-  hipLaunchKernelGGL(x2_prep_weight_kernel, dim3(cblks), dim3(1024), 0, stream, w, (unsigned short*)wx, A, B, NCH, src_ab,
-                     flip, x_slots, nslots, xexps, x_slots == nullptr ? 1 : 0, ofo);
+  hipLaunchKernelGGL(x2_prep_weight_kernel, dim3(cblks * (32 / PREP_ROWS)), dim3(512), 0, stream, w, (unsigned short*)wx, A, B,
+                     NCH, src_ab, flip, x_slots, nslots, xexps, x_slots == nullptr ? 1 : 0, ofo);
   return dca_launch_status();
 }
 
