@@ -72,22 +72,21 @@ constexpr int TD = 4, TH = 8, TW = 16;
 constexpr int ID = TD + 2, IH = TH + 2, IW = TW + 2;
 constexpr int NVOX = ID * IH * IW;                 // 1080 halo voxels
 constexpr int NT = 2;                              // terms per operand
-constexpr int B_TERM = 2 * NVOX * 16;              // bytes of one f16 term image (2 k halves x voxels x 16 B)
-constexpr int B_BYTES = NT * B_TERM;               // 69120
-constexpr int A_SLAB = 9 * NT * 1024;              // 9 taps x 2 terms x (64 lanes x 16 B)
-constexpr int LDS_BYTES = B_BYTES + 2 * A_SLAB;    // 105984 of the CU's 163840
+constexpr int NPAIR = 14;                          // tap pairs (2p, 2p+1): the K = 16 of one MFMA is 8 channels x 2 taps
+constexpr int B_TERM = NVOX * 16;                  // bytes of one f16 term image of an 8-channel chunk (voxels x 16 B)
+constexpr int B_BYTES = NT * B_TERM;               // 34560
+constexpr int A_CHUNK = NPAIR * NT * 1024;         // weight fragments of a chunk: 14 pairs x 2 terms x (64 lanes x 16 B) = 28672
+constexpr int LDS_BYTES = 2 * B_BYTES + 2 * A_CHUNK;   // both images double buffered: 126464 of the CU's 163840
 constexpr int MAX_CIN = 256;                       // the per-channel exponent table below
 constexpr int TAB_BYTES = (MAX_CIN + 32 + 8 * 32) * 4;   // xexps[MAX_CIN] | f_o[32] | per-wave channel maxima [8][32]
-constexpr int NP_ITEMS = NT * 2 * NVOX;            // packed-input staging: 4320 16-byte words per chunk = the LDS image itself
-constexpr int KP = (NP_ITEMS + 511) / 512;         // 9 per thread
-constexpr int KP0 = 5;                             // words 0-4 are requested behind the kd 0 phase, 5-8 behind kd 1
-constexpr int NB_ITEMS = 2 * NVOX;                 // (k half, voxel) staging items of 8 channels (unaligned path)
-constexpr int KB = (NB_ITEMS + 511) / 512;         // 5
-constexpr int NROWS = 2 * ID * IH;                 // 120 (k half, d, h) halo rows: 4 aligned quads + 2 edge voxels each
-constexpr int NQUAD = NROWS * 4, NEDGE = NROWS * 2;  // aligned path: 480 quad items (8 x b128), 240 edge items (8 x b32)
+constexpr int NP_ITEMS = NT * NVOX;                // packed-input staging: 2160 16-byte words per chunk = the LDS image itself
+constexpr int KP = (NP_ITEMS + 511) / 512;         // 5 per thread
+constexpr int KB = (NVOX + 511) / 512;             // 3 single-voxel staging items of 8 channels per thread (unaligned path)
+constexpr int NROWS = ID * IH;                     // 60 (d, h) halo rows: 4 aligned quads + 2 edge voxels each
+constexpr int NQUAD = NROWS * 4, NEDGE = NROWS * 2;  // aligned path: 240 quad items (8 x b128), 120 edge items (8 x b32)
 static_assert(NQUAD <= 512 && NEDGE % 8 == 0 && NEDGE / 8 <= 64, "one quad / edge item per thread");
-constexpr int NA_ITEMS = A_SLAB / 16;              // 1152 b128 per slab
-constexpr int KA = (NA_ITEMS + 511) / 512;         // 3
+constexpr int NA_ITEMS = A_CHUNK / 16;             // 1792 b128 per chunk
+constexpr int KA = (NA_ITEMS + 511) / 512;         // 4
 
 struct X2Args {
   const float* x;
@@ -128,8 +127,8 @@ __device__ __forceinline__ void split2(float v, int e, _Float16& h, _Float16& l)
 template <bool VEC, bool STATS, int EPI, bool PIN>
 __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* b_lds = smem;
-  char* a_lds = smem + B_BYTES;
+  char* b_lds = smem;                               // two halo images (one 8-channel chunk each)
+  char* a_lds = smem + 2 * B_BYTES;                 // two weight-fragment images
   int* xe_lds = (int*)(smem + LDS_BYTES);           // scale exponents of the input channels (fp32 x)
   int* fo_lds = xe_lds + MAX_CIN;                   // f_o of this block's 32 output channels
   float* ycm_lds = (float*)(fo_lds + 32);           // [wave][channel] maxima (y_cmax)
@@ -163,7 +162,7 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
   // the exponent tables were written by the kernels right in front of this one (dca_conv3d_x2_prep_weight / the producer
   // of x): device-coherent vector loads, never s_load (dca_common.h)
   if constexpr (!PIN) {
-    for (int i = tid; i < a.NCH * 16; i += 512) xe_lds[i] = i < a.Cin ? dca_coherent_loadi(a.xexps + i) : 0;
+    for (int i = tid; i < a.NCH * 8; i += 512) xe_lds[i] = i < a.Cin ? dca_coherent_loadi(a.xexps + i) : 0;
   }
   if (tid < 32) fo_lds[tid] = dca_coherent_loadi(a.ofo + cblk * 32 + tid);
   __syncthreads();
@@ -189,13 +188,13 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int r = (wv * 2 + t) * 2 + (l31 >> 4), dl = r >> 3, hl = r & 7;
-    boff[t] = (half * NVOX + (dl * IH + hl) * IW + wlane) * 16;
+    boff[t] = ((dl * IH + hl) * IW + wlane) * 16;
   }
 
   const int cstride = a.D * a.H * a.W;
   const long sample = (long)a.Cin * cstride;
-  const int P = a.NCH * 3;   // phases: (chunk, kd)
-  const long wbytes = (long)P * A_SLAB;
+  const int NC = a.NCH;      // channel chunks of 8 (one MFMA K half)
+  const long wbytes = (long)NC * A_CHUNK;
   const __amdgpu_buffer_rsrc_t wr = dca_rsrc((const char*)a.wx + (long)cblk * wbytes, wbytes);
 
 #if X2_STAMP
@@ -206,27 +205,28 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
 #endif
   const bool has_aff = EPI == 1 && a.scale != nullptr, has_pre = EPI == 1 && a.res_pre != nullptr;
   const bool has_post = EPI == 2 || (EPI == 1 && a.res_post != nullptr);
+  // weight fragments of a chunk: global -> registers (load_A) -> the A image that is not being read (store_A)
   float4 ra[KA];
-  auto load_A = [&](int p) __attribute__((always_inline)) {
+  auto load_A = [&](int chunk) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < KA; ++k) {
       const int it = tid + 512 * k;
-      ra[k] = dca_bload4(wr, p * A_SLAB + it * 16, (int)(it < NA_ITEMS));
+      ra[k] = dca_bload4(wr, chunk * A_CHUNK + it * 16, (int)(it < NA_ITEMS));
     }
   };
   auto store_A = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < KA; ++k) {
       const int it = tid + 512 * k;
-      if (it < NA_ITEMS) *(float4*)(a_lds + buf * A_SLAB + it * 16) = ra[k];
+      if (it < NA_ITEMS) *(float4*)(a_lds + buf * A_CHUNK + it * 16) = ra[k];
     }
   };
 
-  // Staging of a chunk's halo tile, global -> registers (load_B) -> split -> LDS (store_B).
-  //  VEC (W % 4 == 0, 16-byte aligned x): a thread owns one aligned quad of 4 voxels along W (8 x b128, one per
-  //  channel of its k half) and, for tid < 240, one of the two edge voxels of a row (8 x b32): 16 loads per thread.
-  //  Otherwise: 5 single-voxel items of 8 x b32.
-  //  PIN (packed x): 9 16-byte words per thread, word i of the chunk's [term][k half][voxel] image = LDS byte 16 i.
+  // Staging of a chunk's halo tile (8 channels), global -> registers (load_B) -> [split ->] the B image that is not being
+  // read (store_B).
+  //  PIN (packed x): words of the chunk's [term][voxel] image, word i = LDS byte 16 i: 5 per thread, pure copies.
+  //  VEC (fp32 x, W % 4 == 0, 16-byte aligned): threads 0-239 own one aligned quad of 4 voxels along W (8 x b128, one per
+  //  channel), 15 lanes of every wave one of the 120 edge voxels (8 x b32).  Otherwise: 3 single-voxel items of 8 x b32.
   float4 rq[(VEC && !PIN) ? 8 : 1];
   float re[(VEC && !PIN) ? 8 : 1];
   float rb[(VEC || PIN) ? 1 : KB][8];
@@ -235,78 +235,68 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
   if constexpr (PIN) {
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
-      const int it = tid + 512 * k, term = it / (2 * NVOX), rem = it - term * (2 * NVOX), kh = rem / NVOX, v = rem - kh * NVOX;
+      const int it = tid + 512 * k, term = it / NVOX, v = it - term * NVOX;
       const int id = v / (IH * IW), r2 = v - id * (IH * IW), ih = r2 / IW, iw = r2 - ih * IW;
-      item_crd[k] = (it < NP_ITEMS) ? (id | (ih << 8) | (iw << 16) | (kh << 24) | (term << 25)) : -1;
+      item_crd[k] = (it < NP_ITEMS) ? (id | (ih << 8) | (iw << 16) | (term << 25)) : -1;
     }
   } else if constexpr (VEC) {
     {
-      const int row = tid >> 2, q = tid & 3, kh = row / (ID * IH), rem = row - kh * (ID * IH), id = rem / IH, ih = rem - id * IH;
-      item_crd[0] = (tid < NQUAD) ? (id | (ih << 8) | ((1 + 4 * q) << 16) | (kh << 24)) : -1;
+      const int row = tid >> 2, q = tid & 3, id = row / IH, ih = row - id * IH;
+      item_crd[0] = (tid < NQUAD) ? (id | (ih << 8) | ((1 + 4 * q) << 16)) : -1;
     }
-    {  // the 240 edge items dealt evenly over the eight waves (30 lanes each): their scattered 4-byte loads cost the
+    {  // the 120 edge items dealt evenly over the eight waves (15 lanes each): their scattered 4-byte loads cost the
        // memory pipe one cache line per lane, so no wave should carry more of them than the others
       const int e = wv * (NEDGE / 8) + lane;
-      const int row = e >> 1, side = e & 1, kh = row / (ID * IH), rem = row - kh * (ID * IH), id = rem / IH, ih = rem - id * IH;
-      item_crd[1] = (lane < NEDGE / 8) ? (id | (ih << 8) | ((side ? IW - 1 : 0) << 16) | (kh << 24)) : -1;
+      const int row = e >> 1, side = e & 1, id = row / IH, ih = row - id * IH;
+      item_crd[1] = (lane < NEDGE / 8) ? (id | (ih << 8) | ((side ? IW - 1 : 0) << 16)) : -1;
     }
   } else {
 #pragma unroll
     for (int k = 0; k < KB; ++k) {
-      const int it = tid + 512 * k;
-      const int kh = it / NVOX, v = it - kh * NVOX;
+      const int v = tid + 512 * k;
       const int id = v / (IH * IW), rem = v - id * (IH * IW), ih = rem / IW, iw = rem - ih * IW;
-      item_crd[k] = (it < NB_ITEMS) ? (id | (ih << 8) | (iw << 16) | (kh << 24)) : -1;
+      item_crd[k] = (v < NVOX) ? (id | (ih << 8) | (iw << 16)) : -1;
     }
   }
-  auto item_off = [&](int crd, int d0, int h0, int w0, int chunk, int& c0, int& okv) __attribute__((always_inline)) {
+  auto item_off = [&](int crd, int d0, int h0, int w0, int chunk, int& okv) __attribute__((always_inline)) {
     const int di = d0 - 1 + (crd & 255), hi = h0 - 1 + ((crd >> 8) & 255), wi = w0 - 1 + ((crd >> 16) & 255);
-    c0 = chunk * 16 + ((crd >> 24) & 1) * 8;
     okv = (int)(crd >= 0) & (int)((unsigned)di < (unsigned)a.D) & (int)((unsigned)hi < (unsigned)a.H) &
           (int)((unsigned)wi < (unsigned)a.W);
-    return (c0 * cstride + (di * a.H + hi) * a.W + wi) * 4;
+    return (chunk * 8 * cstride + (di * a.H + hi) * a.W + wi) * 4;
   };
-  // VEC: part 0 = channels 0-3 of the thread's quad and of its edge voxel, part 1 = channels 4-7 (a channel's quads and
-  // edge voxels are requested back to back: an edge voxel lies in the 128-byte line of its row's own quads or of the
-  // neighbouring tile's, so half of the edge requests hit lines the quads have just brought into the L1); otherwise
-  // part 0 = items 0-2, part 1 = items 3-4; part -1: everything
-  auto load_B = [&](int part, int n, int d0, int h0, int w0, int chunk) __attribute__((always_inline)) {
+  auto load_B = [&](int n, int d0, int h0, int w0, int chunk) __attribute__((always_inline)) {
     const __amdgpu_buffer_rsrc_t xr = dca_rsrc(a.x + (long)n * sample, sample * 4);
     if constexpr (PIN) {
       // [term][channel group][voxel][8 f16]: the word of (term, group g, voxel v) sits at term * (Cin * S * 2) + (g * S + v) * 16
-      const int tbytes = a.Cin * cstride * 2, ngrp = a.Cin >> 3;
+      const int tbytes = a.Cin * cstride * 2;
 #pragma unroll
       for (int k = 0; k < KP; ++k) {
-        if ((part == 0 && k >= KP0) || (part == 1 && k < KP0)) continue;
         const int crd = item_crd[k];
         const int di = d0 - 1 + (crd & 255), hi = h0 - 1 + ((crd >> 8) & 255), wi = w0 - 1 + ((crd >> 16) & 255);
-        const int g = chunk * 2 + ((crd >> 24) & 1);
         const int ok = (int)(crd >= 0) & (int)((unsigned)di < (unsigned)a.D) & (int)((unsigned)hi < (unsigned)a.H) &
-                       (int)((unsigned)wi < (unsigned)a.W) & (int)(g < ngrp);
-        rp[k] = dca_bload4(xr, ((crd >> 25) & 1) * tbytes + (g * cstride + (di * a.H + hi) * a.W + wi) * 16, ok);
+                       (int)((unsigned)wi < (unsigned)a.W);
+        rp[k] = dca_bload4(xr, ((crd >> 25) & 1) * tbytes + (chunk * cstride + (di * a.H + hi) * a.W + wi) * 16, ok);
       }
     } else if constexpr (VEC) {
-      int c0, okq, c0e, oke;
-      const int offq = item_off(item_crd[0], d0, h0, w0, chunk, c0, okq);  // a quad is inside W or outside as a whole
-      const int offe = item_off(item_crd[1], d0, h0, w0, chunk, c0e, oke);
+      int okq, oke;
+      const int offq = item_off(item_crd[0], d0, h0, w0, chunk, okq);  // a quad is inside W or outside as a whole
+      const int offe = item_off(item_crd[1], d0, h0, w0, chunk, oke);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        if ((part == 0 && j >= 4) || (part == 1 && j < 4)) continue;
-        rq[j] = dca_bload4(xr, offq + j * cstride * 4, okq & (int)(c0 + j < a.Cin));
-        re[j] = dca_bload1(xr, offe + j * cstride * 4, oke & (int)(c0e + j < a.Cin));
+        rq[j] = dca_bload4(xr, offq + j * cstride * 4, okq & (int)(chunk * 8 + j < a.Cin));
+        re[j] = dca_bload1(xr, offe + j * cstride * 4, oke & (int)(chunk * 8 + j < a.Cin));
       }
     } else {
 #pragma unroll
       for (int k = 0; k < KB; ++k) {
-        if ((part == 0 && k >= 3) || (part == 1 && k < 3)) continue;
-        int c0, okv;
-        const int off = item_off(item_crd[k], d0, h0, w0, chunk, c0, okv);
+        int okv;
+        const int off = item_off(item_crd[k], d0, h0, w0, chunk, okv);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) rb[k][j] = dca_bload1(xr, off + j * cstride * 4, okv & (int)(c0 + j < a.Cin));
+        for (int j = 0; j < 8; ++j) rb[k][j] = dca_bload1(xr, off + j * cstride * 4, okv & (int)(chunk * 8 + j < a.Cin));
       }
     }
   };
-  auto split_store = [&](const float (&v)[8], const int* ex, int vox_off) __attribute__((always_inline)) {
+  auto split_store = [&](const float (&v)[8], const int* ex, char* dst) __attribute__((always_inline)) {
     const int4 e0 = *(const int4*)ex, e1 = *(const int4*)(ex + 4);     // the 8 channels' exponents (LDS table)
     const int e[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
     f16x8 hv, lv;
@@ -316,22 +306,23 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
       split2(v[j], e[j], h, l);
       hv[j] = h; lv[j] = l;
     }
-    *(f16x8*)(b_lds + vox_off) = hv;
-    *(f16x8*)(b_lds + B_TERM + vox_off) = lv;
+    *(f16x8*)dst = hv;
+    *(f16x8*)(dst + B_TERM) = lv;
   };
   auto crd_lds = [&](int crd) __attribute__((always_inline)) {  // byte offset of the item's (first) voxel in a term image
-    return ((((crd >> 24) & 1) * ID + (crd & 255)) * IH + ((crd >> 8) & 255)) * IW * 16 + ((crd >> 16) & 255) * 16;
+    return (((crd & 255) * IH + ((crd >> 8) & 255)) * IW + ((crd >> 16) & 255)) * 16;
   };
-  // chunk = the channel chunk the staged registers belong to (its exponents)
-  auto store_B = [&](int chunk) __attribute__((always_inline)) {
+  // chunk = the channel chunk the staged registers belong to (its exponents); buf = the B image to fill
+  auto store_B = [&](int chunk, int buf) __attribute__((always_inline)) {
+    char* img = b_lds + buf * B_BYTES;
     if constexpr (PIN) {
 #pragma unroll
       for (int k = 0; k < KP; ++k)
-        if (item_crd[k] >= 0) *(float4*)(b_lds + (tid + 512 * k) * 16) = rp[k];
+        if (item_crd[k] >= 0) *(float4*)(img + (tid + 512 * k) * 16) = rp[k];
     } else if constexpr (VEC) {
+      const int* ex = xe_lds + chunk * 8;
       if (item_crd[0] >= 0) {
-        const int* ex = xe_lds + chunk * 16 + ((item_crd[0] >> 24) & 1) * 8;
-        const int o = crd_lds(item_crd[0]);
+        char* o = img + crd_lds(item_crd[0]);
         const float v0[8] = {rq[0].x, rq[1].x, rq[2].x, rq[3].x, rq[4].x, rq[5].x, rq[6].x, rq[7].x};
         const float v1[8] = {rq[0].y, rq[1].y, rq[2].y, rq[3].y, rq[4].y, rq[5].y, rq[6].y, rq[7].y};
         const float v2[8] = {rq[0].z, rq[1].z, rq[2].z, rq[3].z, rq[4].z, rq[5].z, rq[6].z, rq[7].z};
@@ -340,12 +331,13 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
       }
       if (item_crd[1] >= 0) {
         const float v[8] = {re[0], re[1], re[2], re[3], re[4], re[5], re[6], re[7]};
-        split_store(v, xe_lds + chunk * 16 + ((item_crd[1] >> 24) & 1) * 8, crd_lds(item_crd[1]));
+        split_store(v, ex, img + crd_lds(item_crd[1]));
       }
     } else {
+      const int* ex = xe_lds + chunk * 8;
 #pragma unroll
       for (int k = 0; k < KB; ++k)
-        if (item_crd[k] >= 0) split_store(rb[k], xe_lds + chunk * 16 + ((item_crd[k] >> 24) & 1) * 8, crd_lds(item_crd[k]));
+        if (item_crd[k] >= 0) split_store(rb[k], ex, img + crd_lds(item_crd[k]));
     }
   };
   auto decode = [&](int tile, int& n, int& d0, int& h0, int& w0) __attribute__((always_inline)) {
@@ -358,14 +350,13 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
 
   int n, d0, h0, w0;
   decode(t_begin, n, d0, h0, w0);
-  load_B(-1, n, d0, h0, w0, 0);
+  load_B(n, d0, h0, w0, 0);
   load_A(0);
-  store_B(0);
+  store_B(0, 0);
   store_A(0);
-  load_A(1);   // P >= 3
   __syncthreads();
 
-  int buf = 0;  // A slab buffer of the current phase (phases alternate buffers across chunk and tile boundaries)
+  int buf = 0;  // image pair (A, B) of the current chunk; chunks alternate buffers across tile boundaries
 #pragma unroll 1
   for (int tile = t_begin; tile < t_end; tile += t_step) {
     const bool more_tiles = tile + t_step < t_end;
@@ -375,97 +366,75 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     int nn = n, nd0 = d0, nh0 = h0, nw0 = w0;  // coordinates of the next tile (valid when more_tiles)
+    if (more_tiles) decode(tile + t_step, nn, nd0, nh0, nw0);
 
 #pragma unroll 1
-    for (int p = 0; p < P; ++p, buf ^= 1) {
-      const int chunk = p / 3, kd = p - chunk * 3;
-      const bool last_chunk = chunk + 1 == a.NCH;
-      // the halo tile of the next chunk / of chunk 0 of the next tile is fetched during this chunk: half of the loads
-      // behind the MFMAs of phase kd 0, half behind those of kd 1 (all 16 loads in one 54-MFMA phase stretched it from
-      // 2.6 k to 8-10 k cycles: s_memtime stamps, tools/x2_stamps.py), split and stored after kd 2
+    for (int chunk = 0; chunk < NC; ++chunk, buf ^= 1) {
+      const bool last_chunk = chunk + 1 == NC;
+      // The halo tile and the weight fragments of the NEXT chunk (of chunk 0 of the next tile) are fetched while this chunk
+      // computes and written into the other image pair: nobody reads that pair before the barrier at the end of the chunk,
+      // so the loads, the [split and] LDS stores and the MFMAs of a chunk need no ordering among themselves -- ONE barrier
+      // per chunk of 84 MFMAs per wave (round 2: three phases of 54 with a barrier each, the slab stores in front of each
+      // phase and the halo image written between two extra barriers after every third).
       const bool stage = !last_chunk || more_tiles;
       const bool next_tile = last_chunk && more_tiles;
       X2_MARK(0);
-#if X2_LD_FRONT == 1
-      // the staging part's global loads in front of the slab stores: the matrix pipe is idle there anyway
-      if (stage && kd < 2) {
-        const bool nt = next_tile;
-        if (nt && kd == 0) decode(tile + t_step, nn, nd0, nh0, nw0);
-        load_B(kd, nt ? nn : n, nt ? nd0 : d0, nt ? nh0 : h0, nt ? nw0 : w0, nt ? 0 : chunk + 1);
+      if (stage) {
+        load_B(next_tile ? nn : n, next_tile ? nd0 : d0, next_tile ? nh0 : h0, next_tile ? nw0 : w0, next_tile ? 0 : chunk + 1);
+        load_A(next_tile ? 0 : chunk + 1);
       }
-#endif
-      // slab p+1 (in registers since the previous phase) -> the buffer phase p-1 used; then fetch slab p+2
-      if (p + 1 < P || more_tiles) store_A(buf ^ 1);
-      if (p + 2 < P || more_tiles) load_A(p + 2 < P ? p + 2 : p + 2 - P);
-#if X2_LD_FRONT != 1
-      if (next_tile && kd == 0) decode(tile + t_step, nn, nd0, nh0, nw0);
-#endif
-      const char* ab = a_lds + buf * A_SLAB + lane * 16;
-      const char* bb = b_lds + kd * (IH * IW * 16);
-      // The 9 taps of the slab with a register double buffer: the 6 ds_read_b128 of tap+1 go one per MFMA between
-      // the 6 MFMAs of tap, and the global loads of a staging part are spread over the taps as well (all issued up
-      // front they fill the CU's memory queue and the waves sit in the issue stage for microseconds with the matrix
-      // pipe idle).  sched_group_barrier pins the order; left alone, hipcc issues each LDS read right before its first
-      // use and waits on it.
-      auto phase = [&](auto PART) __attribute__((always_inline)) {
-        constexpr int LD = decltype(PART)::value;        // -1: no loads, 0 / 1: staging part
-        constexpr int NLD = LD < 0 ? 0 : ((VEC || PIN) ? 1 : (LD == 0 ? 3 : 2));  // global loads per tap (8 taps)
-        if constexpr (LD >= 0) {
-          const bool nt = next_tile;
-          load_B(LD, nt ? nn : n, nt ? nd0 : d0, nt ? nh0 : h0, nt ? nw0 : w0, nt ? 0 : chunk + 1);
-        }
-        f16x8 fa[2][NT], fb[2][2][NT];
-        auto load_frag = [&](int tap9, int slot) __attribute__((always_inline)) {
-          const int kh = tap9 / 3, kw = tap9 - kh * 3;
+      const char* ab = a_lds + buf * A_CHUNK + lane * 16;
+      const char* bb = b_lds + buf * B_BYTES;
+      // 14 tap pairs with a register double buffer: the 6 ds_read_b128 of pair p+1 go one per MFMA between the 6 MFMAs of
+      // pair p, the staging loads one per pair behind them.  sched_group_barrier pins the order; left alone, hipcc issues
+      // each LDS read right before its first use and waits on it.
+      f16x8 fa[2][NT], fb[2][2][NT];
+      auto load_frag = [&](int p, int slot) __attribute__((always_inline)) {
+        // lanes 0-31 hold k = the chunk's 8 channels at tap 2p, lanes 32-63 the same channels at tap 2p+1 (the 28th "tap"
+        // has zero weights: any finite B data will do, tap 26's)
+        const int t0 = 2 * p, t1 = (2 * p + 1 < 27) ? 2 * p + 1 : 26;
+        const int o0 = (((t0 / 9) * IH + (t0 / 3) % 3) * IW + t0 % 3) * 16, o1 = (((t1 / 9) * IH + (t1 / 3) % 3) * IW + t1 % 3) * 16;
+        const int toff = half ? o1 : o0;
 #pragma unroll
-          for (int term = 0; term < NT; ++term) fa[slot][term] = *(const f16x8*)(ab + (tap9 * NT + term) * 1024);
+        for (int term = 0; term < NT; ++term) fa[slot][term] = *(const f16x8*)(ab + (p * NT + term) * 1024);
 #pragma unroll
-          for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int term = 0; term < NT; ++term)
-              fb[slot][t][term] = *(const f16x8*)(bb + boff[t] + (kh * IW + kw) * 16 + term * B_TERM);
-        };
-        load_frag(0, 0);
-#pragma unroll
-        for (int tap9 = 0; tap9 < 9; ++tap9) {
-          const int cur = tap9 & 1;
-          if (tap9 < 8) load_frag(tap9 + 1, cur ^ 1);
-          // smallest terms first; the two column tiles alternate so consecutive MFMAs never chain on one accumulator
-          constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};
-#pragma unroll
-          for (int q = 0; q < 3; ++q)
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][PA[q]], fb[cur][t][PB[q]], acc[t], 0, 0, 0);
-          if (tap9 < 8) {
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-              if (i < (X2_LD_FRONT == 2 ? (tap9 < 4 ? 2 * NLD : 0) : NLD)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            }
-          }
-        }
+          for (int term = 0; term < NT; ++term)
+            fb[slot][t][term] = *(const f16x8*)(bb + boff[t] + toff + term * B_TERM);
       };
       X2_MARK(1);
-#if X2_LD_FRONT == 1
-      phase(std::integral_constant<int, -1>{});
-#else
-      if (stage && kd == 0) phase(std::integral_constant<int, 0>{});
-      else if (stage && kd == 1) phase(std::integral_constant<int, 1>{});
-      else phase(std::integral_constant<int, -1>{});
-#endif
-      X2_MARK(2);
-      if (stage && kd == 2) {
-        __syncthreads();  // every wave is done reading the halo tile of this chunk
-        X2_MARK(3);
-        store_B(next_tile ? 0 : chunk + 1);
-        X2_MARK(4);
+      load_frag(0, 0);
+#pragma unroll
+      for (int p = 0; p < NPAIR; ++p) {
+        const int cur = p & 1;
+        if (p + 1 < NPAIR) load_frag(p + 1, cur ^ 1);
+        // smallest terms first; the two column tiles alternate so consecutive MFMAs never chain on one accumulator
+        constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][PA[q]], fb[cur][t][PB[q]], acc[t], 0, 0, 0);
+        if (p + 1 < NPAIR) {
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (i < 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          }
+        }
       }
+      X2_MARK(2);
+      if (stage) {
+        store_B(next_tile ? 0 : chunk + 1, buf ^ 1);
+        store_A(buf ^ 1);
+      }
+      X2_MARK(3);
       __syncthreads();
       X2_MARK(5);
 #if X2_STAMP
-      if (p + 1 < P) ++stamp_k;
+      if (chunk + 1 < NC) ++stamp_k;
 #endif
     }
     X2_MARK(6);
@@ -589,9 +558,9 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
 //   1. xexps[k]: given, or (slots != null) derived here from the operand's per-channel maxima and written out for the
 //      weight-gradient kernel that reads the same operand later;
 //   2. f_o = 14 - max over (k, tap) of (exponent of w[o][k][tap]) - xexps[k]: the row's largest scaled entry in [2^14, 2^15);
-//   3. wx[cblk][chunk][tap][term][lane][j] (f16): lane (r = lane & 31, h = lane >> 5) holds A[row = output channel
-//      cblk*32 + r][k = input channel chunk*16 + 8h + j] of the tap = w 2^(f_o - xexps[k]), split into term 0/1 = h/l;
-//      zero padded;  f_o goes behind the images (ofo[cblk*32 + r]).
+//   3. wx[cblk][chunk of 8 channels][tap pair p][term][lane][j] (f16): lane (r = lane & 31, h = lane >> 5) holds
+//      A[row = output channel cblk*32 + r][k = (input channel chunk*8 + j, tap 2p + h)] = w 2^(f_o - xexps[channel]), split
+//      into term 0/1 = h/l; zero padded (channels beyond Cin, the 28th tap);  f_o goes behind the images (ofo[cblk*32 + r]).
 // Source indexing as dca_conv3d_prep_weight: src_ab ? src[a][b][27] : src[b][a][27]; flip reverses the tap order.
 constexpr int PREP_ROWS = 4;       // output channels per workgroup of the packing kernel (8 workgroups per block of 32)
 __global__ __launch_bounds__(512) void x2_prep_weight_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
@@ -644,19 +613,21 @@ __global__ __launch_bounds__(512) void x2_prep_weight_kernel(const float* __rest
     ofo[cblk * 32 + r0 + tid] = fo;
   }
   __syncthreads();
-  // items (chunk, tap, k half, row): the 8 input channels of one lane's fragment, both terms: two 16-byte stores
-  const int nitems = NCH * 27 * 2 * PREP_ROWS;
-  unsigned short* out = dst + (long)cblk * NCH * 27 * NT * 512;
+  // items (chunk of 8 channels, tap pair, k half = tap of the pair, row): the 8 input channels of one lane's fragment,
+  // both terms: two 16-byte stores
+  const int nitems = NCH * NPAIR * 2 * PREP_ROWS;
+  unsigned short* out = dst + (long)cblk * NCH * NPAIR * NT * 512;
   for (int it = tid; it < nitems; it += 512) {
-    const int r = it % PREP_ROWS, hf = (it / PREP_ROWS) & 1, t = it / (2 * PREP_ROWS), tap = t % 27, chunk = t / 27;
+    const int r = it % PREP_ROWS, hf = (it / PREP_ROWS) & 1, t = it / (2 * PREP_ROWS), pair = t % NPAIR, chunk = t / NPAIR;
+    const int tap = 2 * pair + hf;
     const int bi = cblk * 32 + r0 + r, st = flip ? 26 - tap : tap, fo = rowmax[r][0];
     f16x8 hv, lv;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int ai = chunk * 16 + 8 * hf + j;
+      const int ai = chunk * 8 + j;
       float v = 0.f;
       int e = 0;
-      if (ai < A && bi < Bn) {
+      if (ai < A && bi < Bn && tap < 27) {
         v = src_ab ? src[((long)ai * Bn + bi) * 27 + st] : src[((long)bi * A + ai) * 27 + st];
         e = fo - xe[ai];
       }
@@ -664,7 +635,7 @@ __global__ __launch_bounds__(512) void x2_prep_weight_kernel(const float* __rest
       split2(v, e, h, l);
       hv[j] = h; lv[j] = l;
     }
-    const long o = ((long)(chunk * 27 + tap) * NT) * 512 + (hf * 32 + r0 + r) * 8;      // f16 elements; term stride 512
+    const long o = ((long)(chunk * NPAIR + pair) * NT) * 512 + (hf * 32 + r0 + r) * 8;      // f16 elements; term stride 512
     *(f16x8*)(out + o) = hv;
     *(f16x8*)(out + o + 512) = lv;
   }
@@ -675,7 +646,7 @@ __global__ __launch_bounds__(512) void x2_prep_weight_kernel(const float* __rest
 // bytes of the packed image: fragments, then f_o (one int per output channel, padded to blocks of 32)
 extern "C" long dca_conv3d_x2_weight_bytes(int Cin, int Cout) {
   if (Cin <= 0 || Cout <= 0) return 0;
-  return (long)((Cout + 31) / 32) * ((Cin + 15) / 16) * 27 * NT * 1024 + (long)((Cout + 31) / 32) * 32 * 4;
+  return (long)((Cout + 31) / 32) * ((Cin + 7) / 8) * A_CHUNK + (long)((Cout + 31) / 32) * 32 * 4;
 }
 
 // Packs w for ONE convolution launch over an operand with the per-channel scale exponents xexps (A ints).
@@ -686,8 +657,8 @@ extern "C" int dca_conv3d_x2_prep_weight(const float* w, void* wx, int A, int B,
                                          const unsigned* x_slots, int nslots, int* xexps, hipStream_t stream) {
   DCA_REQUIRE(w && wx && xexps && A > 0 && A <= MAX_CIN && B > 0 && ((((uintptr_t)wx) & 15) == 0));
   DCA_REQUIRE(x_slots == nullptr || (nslots > 0 && nslots <= DCA_AMAX_CSLOTS));
-  const int NCH = (A + 15) / 16, cblks = (B + 31) / 32;
-  int* ofo = (int*)((char*)wx + (long)cblks * NCH * 27 * NT * 1024);
+  const int NCH = (A + 7) / 8, cblks = (B + 31) / 32;
+  int* ofo = (int*)((char*)wx + (long)cblks * NCH * A_CHUNK);
   hipLaunchKernelGGL(x2_prep_weight_kernel, dim3(cblks * (32 / PREP_ROWS)), dim3(512), 0, stream, w, (unsigned short*)wx, A, B,
                      NCH, src_ab, flip, x_slots, nslots, xexps, x_slots == nullptr ? 1 : 0, ofo);
   return dca_launch_status();
@@ -730,14 +701,14 @@ int x2_launch(const void* x, int packed, const int* xexps, const void* wx, float
   X2Args a;
   a.x = (const float*)x; a.wx = (const unsigned short*)wx; a.y = y;
   a.scale = scale; a.shift = shift; a.res_pre = res_pre; a.res_post = res_post; a.slope = slope;
-  a.N = N; a.Cin = Cin; a.Cout = Cout; a.NCH = (Cin + 15) / 16;
+  a.N = N; a.Cin = Cin; a.Cout = Cout; a.NCH = (Cin + 7) / 8;
   a.D = D; a.H = H; a.W = W;
   a.nTD = cdiv(D, TD); a.nTH = cdiv(H, TH); a.nTW = cdiv(W, TW);
   a.stat_part = stat_part;
   a.xexps = xexps;
   a.y_cmax = y_cmax;
   const int cblks = (Cout + 31) / 32;
-  a.ofo = (const int*)((const char*)wx + (long)cblks * a.NCH * 27 * NT * 1024);
+  a.ofo = (const int*)((const char*)wx + (long)cblks * a.NCH * A_CHUNK);
   const long tiles = (long)N * a.nTD * a.nTH * a.nTW;
   DCA_REQUIRE(tiles < 0x7fffffffL && cblks <= 65535);
   const bool vec = (W % 4 == 0) && ((((uintptr_t)x) & 15) == 0);
