@@ -50,8 +50,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #ifndef X2_NT
 #define X2_NT 0
 #endif
-// X2_STAMP (debug build, tools/x3_stamps.py, f16x2 build): res_post is reinterpreted as an unsigned long long buffer that receives
-// s_memtime stamps of the first 96 phases (8 per phase) of workgroup 0, wave 0
+// X2_STAMP (debug build, tools/x2_stamps.py): dca_x2_debug_set_stamps(ptr) names a buffer of 2 x 96 x 8 unsigned long long that
+// receives s_memtime stamps of the first 96 chunks (8 marks per chunk) of workgroup 0, waves 0 and 7
 #ifndef X2_STAMP
 #define X2_STAMP 0
 #endif
@@ -104,6 +104,9 @@ struct X2Args {
   const int* xexps;          // fp32 x: the scale exponent of every input channel (Cin ints); unused for packed x
   const int* ofo;            // behind the packed weight image: f_o of every output channel (dca_conv3d_x2_prep_weight)
   unsigned* y_cmax;          // optional (EPI 1): per-channel slots [c][blockIdx.x] that receive max |y| (dca_common.h)
+#if X2_STAMP
+  unsigned long long* stamps;   // debug build: s_memtime stamps of workgroup 0, waves 0 and 7 (2 x 96 x 8 words)
+#endif
 };
 
 constexpr int STAT_LDS = 8 * FS_WAVE_FLOATS * 4;
@@ -198,9 +201,9 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
   const __amdgpu_buffer_rsrc_t wr = dca_rsrc((const char*)a.wx + (long)cblk * wbytes, wbytes);
 
 #if X2_STAMP
-  unsigned long long* stamps = (unsigned long long*)a.res_post;
-  a.res_post = nullptr;
-  const bool stamp_on = blockIdx.x == 0 && blockIdx.y == 0 && wv == 0;
+  unsigned long long* stamps = a.stamps;
+  const bool stamp_on = stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && (wv == 0 || wv == 7);
+  if (stamp_on && wv == 7) stamps += 96 * 8;
   int stamp_k = 0;
 #endif
   const bool has_aff = EPI == 1 && a.scale != nullptr, has_pre = EPI == 1 && a.res_pre != nullptr;
@@ -664,6 +667,11 @@ extern "C" int dca_conv3d_x2_prep_weight(const float* w, void* wx, int A, int B,
   return dca_launch_status();
 }
 
+#if X2_STAMP
+static unsigned long long* g_stamps = nullptr;
+extern "C" void dca_x2_debug_set_stamps(unsigned long long* p) { g_stamps = p; }
+#endif
+
 namespace {
 
 int x2_grid(long tiles, int cblks) {
@@ -707,6 +715,9 @@ int x2_launch(const void* x, int packed, const int* xexps, const void* wx, float
   a.stat_part = stat_part;
   a.xexps = xexps;
   a.y_cmax = y_cmax;
+#if X2_STAMP
+  a.stamps = g_stamps;
+#endif
   const int cblks = (Cout + 31) / 32;
   a.ofo = (const int*)((const char*)wx + (long)cblks * a.NCH * A_CHUNK);
   const long tiles = (long)N * a.nTD * a.nTH * a.nTW;

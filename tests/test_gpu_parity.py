@@ -601,9 +601,10 @@ def test_f16x2_per_channel_scales(spread, monkeypatch):
     channels' scales.  Operand channels spread over `spread` (1e2 ... 1e8) and a BLOCK-DIAGONAL weight, so that output
     channel o reads input channel o alone: the error of every output channel, relative to THAT channel's maximum, must not
     depend on the spread -- forward, backward-data (per-channel spread of dy) and both weight gradients (stride 1 and
-    stride 2; per-channel spreads of x and dy; dW[o][i] relative to its own (o, i) block).  Gate: within 3x of the fp32-MFMA
+    stride 2; per-channel spreads of x and dy; dW[o][i] relative to its own (o, i) block).  Gate: within 4x of the fp32-MFMA
     kernel's per-channel error (an f16 pair carries 22 bits against fp32's 24: with only 27 products per output the operand
-    representation, not the accumulation, sets the error) and below 1e-6 absolutely."""
+    representation, not the accumulation, sets the error -- 2^-22 per operand, 2^-21 per product) and below 1e-6 absolutely,
+    the SAME for every spread."""
     _, ops = _mods()
     C, dims = 32, (4, 8, 16)
     g = torch.Generator().manual_seed(11)
@@ -627,12 +628,12 @@ def test_f16x2_per_channel_scales(spread, monkeypatch):
     got, base = run("f16x2"), run("fp32mfma")
     for name, a, b, ref in (("fwd", got[0], base[0], yr), ("dx", got[1], base[1], gxr)):
         e2, e32 = _chan_err(a, ref), _chan_err(b, ref)
-        assert (e2 <= 3.0 * e32 + 1e-7).all() and e2.max() <= 1e-6, (name, spread, e2.max().item(), e32.max().item())
+        assert (e2 <= 4.0 * e32 + 2e-7).all() and e2.max() <= 1e-6, (name, spread, e2.max().item(), e32.max().item())
     # weight gradient: the (o, o) diagonal blocks carry the products of channel o of dy and channel o of x
     diag = lambda t: t.detach().cpu().double()[torch.arange(C), torch.arange(C)]          # (C, 3, 3, 3)
     e2 = (diag(got[2]) - diag(gwr)).abs().amax((1, 2, 3)) / diag(gwr).abs().amax((1, 2, 3))
     e32 = (diag(base[2]) - diag(gwr)).abs().amax((1, 2, 3)) / diag(gwr).abs().amax((1, 2, 3))
-    assert (e2 <= 3.0 * e32 + 2e-7).all() and e2.max() <= 1e-6, ("dw", spread, e2.max().item(), e32.max().item())
+    assert (e2 <= 4.0 * e32 + 2e-7).all() and e2.max() <= 1e-6, ("dw", spread, e2.max().item(), e32.max().item())
     # stride-2 weight gradient (conv3d_wgrad_s2_f16x2.hip): coarse dy (2, C, 2, 4, 8)
     dyc = torch.randn(2, C, 2, 4, 8, generator=g) * sd.view(1, C, 1, 1, 1)
     ref2 = torch.nn.grad.conv3d_weight(x.double(), (C, C, 3, 3, 3), dyc.double(), stride=2, padding=1)
@@ -645,7 +646,7 @@ def test_f16x2_per_channel_scales(spread, monkeypatch):
         # every (o, i) block relative to its own maximum: the blocks differ by up to spread^2
         blk = lambda t: t.detach().cpu().double().reshape(C, C, 27)
         res[on] = ((blk(gw2) - blk(ref2)).abs().amax(2) / blk(ref2).abs().amax(2)).max().item()
-    assert res[True] <= 3.0 * res[False] + 2e-7 and res[True] <= 1e-6, (spread, res)
+    assert res[True] <= 4.0 * res[False] + 2e-7 and res[True] <= 1e-6, (spread, res)
 
 
 def test_f16x2_tiny_gradients(monkeypatch):
