@@ -210,19 +210,23 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
   const bool has_post = EPI == 2 || (EPI == 1 && a.res_post != nullptr);
   // weight fragments of a chunk: global -> registers (load_A) -> the A image that is not being read (store_A)
   float4 ra[KA];
+  // `on` (0 / 1, wave uniform): the last chunk of a workgroup's last tile has nothing to stage -- its loads are masked off
+  // (no control flow inside the MFMA stream) and its stores write zeros into an image nobody reads any more
+  auto load_A_item = [&](int k, int chunk, int on) __attribute__((always_inline)) {
+    const int it = tid + 512 * k;
+    ra[k] = dca_bload4(wr, chunk * A_CHUNK + it * 16, (int)(it < NA_ITEMS) & on);
+  };
+  auto store_A_item = [&](int k, int buf) __attribute__((always_inline)) {
+    const int it = tid + 512 * k;
+    if (it < NA_ITEMS) *(float4*)(a_lds + buf * A_CHUNK + it * 16) = ra[k];
+  };
   auto load_A = [&](int chunk) __attribute__((always_inline)) {
 #pragma unroll
-    for (int k = 0; k < KA; ++k) {
-      const int it = tid + 512 * k;
-      ra[k] = dca_bload4(wr, chunk * A_CHUNK + it * 16, (int)(it < NA_ITEMS));
-    }
+    for (int k = 0; k < KA; ++k) load_A_item(k, chunk, 1);
   };
   auto store_A = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int k = 0; k < KA; ++k) {
-      const int it = tid + 512 * k;
-      if (it < NA_ITEMS) *(float4*)(a_lds + buf * A_CHUNK + it * 16) = ra[k];
-    }
+    for (int k = 0; k < KA; ++k) store_A_item(k, buf);
   };
 
   // Staging of a chunk's halo tile (8 channels), global -> registers (load_B) -> [split ->] the B image that is not being
@@ -267,28 +271,32 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
           (int)((unsigned)wi < (unsigned)a.W);
     return (chunk * 8 * cstride + (di * a.H + hi) * a.W + wi) * 4;
   };
-  auto load_B = [&](int n, int d0, int h0, int w0, int chunk) __attribute__((always_inline)) {
-    const __amdgpu_buffer_rsrc_t xr = dca_rsrc(a.x + (long)n * sample, sample * 4);
+  // one staging step of the halo tile, k = 0 .. NLB-1: PIN: word k of the thread; VEC: channel k of its quad and of its
+  // edge voxel; (otherwise load_B loads everything at once)
+  constexpr int NLB = PIN ? KP : 8;
+  auto load_B_item = [&](int k, __amdgpu_buffer_rsrc_t xr, int d0, int h0, int w0, int chunk, int on) __attribute__((always_inline)) {
     if constexpr (PIN) {
       // [term][channel group][voxel][8 f16]: the word of (term, group g, voxel v) sits at term * (Cin * S * 2) + (g * S + v) * 16
       const int tbytes = a.Cin * cstride * 2;
-#pragma unroll
-      for (int k = 0; k < KP; ++k) {
-        const int crd = item_crd[k];
-        const int di = d0 - 1 + (crd & 255), hi = h0 - 1 + ((crd >> 8) & 255), wi = w0 - 1 + ((crd >> 16) & 255);
-        const int ok = (int)(crd >= 0) & (int)((unsigned)di < (unsigned)a.D) & (int)((unsigned)hi < (unsigned)a.H) &
-                       (int)((unsigned)wi < (unsigned)a.W);
-        rp[k] = dca_bload4(xr, ((crd >> 25) & 1) * tbytes + (chunk * cstride + (di * a.H + hi) * a.W + wi) * 16, ok);
-      }
+      const int crd = item_crd[k];
+      const int di = d0 - 1 + (crd & 255), hi = h0 - 1 + ((crd >> 8) & 255), wi = w0 - 1 + ((crd >> 16) & 255);
+      const int ok = (int)(crd >= 0) & (int)((unsigned)di < (unsigned)a.D) & (int)((unsigned)hi < (unsigned)a.H) &
+                     (int)((unsigned)wi < (unsigned)a.W) & on;
+      rp[k] = dca_bload4(xr, ((crd >> 25) & 1) * tbytes + (chunk * cstride + (di * a.H + hi) * a.W + wi) * 16, ok);
     } else if constexpr (VEC) {
       int okq, oke;
       const int offq = item_off(item_crd[0], d0, h0, w0, chunk, okq);  // a quad is inside W or outside as a whole
       const int offe = item_off(item_crd[1], d0, h0, w0, chunk, oke);
+      const int okc = (int)(chunk * 8 + k < a.Cin) & on;
+      rq[k] = dca_bload4(xr, offq + k * cstride * 4, okq & okc);
+      re[k] = dca_bload1(xr, offe + k * cstride * 4, oke & okc);
+    }
+  };
+  auto load_B = [&](int n, int d0, int h0, int w0, int chunk) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t xr = dca_rsrc(a.x + (long)n * sample, sample * 4);
+    if constexpr (PIN || VEC) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        rq[j] = dca_bload4(xr, offq + j * cstride * 4, okq & (int)(chunk * 8 + j < a.Cin));
-        re[j] = dca_bload1(xr, offe + j * cstride * 4, oke & (int)(chunk * 8 + j < a.Cin));
-      }
+      for (int k = 0; k < NLB; ++k) load_B_item(k, xr, d0, h0, w0, chunk, 1);
     } else {
 #pragma unroll
       for (int k = 0; k < KB; ++k) {
@@ -315,27 +323,32 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
   auto crd_lds = [&](int crd) __attribute__((always_inline)) {  // byte offset of the item's (first) voxel in a term image
     return (((crd & 255) * IH + ((crd >> 8) & 255)) * IW + ((crd >> 16) & 255)) * 16;
   };
-  // chunk = the channel chunk the staged registers belong to (its exponents); buf = the B image to fill
-  auto store_B = [&](int chunk, int buf) __attribute__((always_inline)) {
+  // chunk = the channel chunk the staged registers belong to (its exponents); buf = the B image to fill.
+  // store_B_item: one step, k = 0 .. NSB-1 (PIN: word k; VEC: voxel k of the quad, k = 4: the edge voxel)
+  constexpr int NSB = PIN ? KP : 5;
+  auto store_B_item = [&](int k, int chunk, int buf) __attribute__((always_inline)) {
     char* img = b_lds + buf * B_BYTES;
     if constexpr (PIN) {
-#pragma unroll
-      for (int k = 0; k < KP; ++k)
-        if (item_crd[k] >= 0) *(float4*)(img + (tid + 512 * k) * 16) = rp[k];
+      if (item_crd[k] >= 0) *(float4*)(img + (tid + 512 * k) * 16) = rp[k];
     } else if constexpr (VEC) {
       const int* ex = xe_lds + chunk * 8;
-      if (item_crd[0] >= 0) {
-        char* o = img + crd_lds(item_crd[0]);
-        const float v0[8] = {rq[0].x, rq[1].x, rq[2].x, rq[3].x, rq[4].x, rq[5].x, rq[6].x, rq[7].x};
-        const float v1[8] = {rq[0].y, rq[1].y, rq[2].y, rq[3].y, rq[4].y, rq[5].y, rq[6].y, rq[7].y};
-        const float v2[8] = {rq[0].z, rq[1].z, rq[2].z, rq[3].z, rq[4].z, rq[5].z, rq[6].z, rq[7].z};
-        const float v3[8] = {rq[0].w, rq[1].w, rq[2].w, rq[3].w, rq[4].w, rq[5].w, rq[6].w, rq[7].w};
-        split_store(v0, ex, o); split_store(v1, ex, o + 16); split_store(v2, ex, o + 32); split_store(v3, ex, o + 48);
-      }
-      if (item_crd[1] >= 0) {
+      if (k < 4) {
+        if (item_crd[0] >= 0) {
+          const float* q0 = (const float*)&rq[0];
+          const float v[8] = {q0[k], q0[4 + k], q0[8 + k], q0[12 + k], q0[16 + k], q0[20 + k], q0[24 + k], q0[28 + k]};
+          split_store(v, ex, img + crd_lds(item_crd[0]) + 16 * k);
+        }
+      } else if (item_crd[1] >= 0) {
         const float v[8] = {re[0], re[1], re[2], re[3], re[4], re[5], re[6], re[7]};
         split_store(v, ex, img + crd_lds(item_crd[1]));
       }
+    }
+  };
+  auto store_B = [&](int chunk, int buf) __attribute__((always_inline)) {
+    char* img = b_lds + buf * B_BYTES;
+    if constexpr (PIN || VEC) {
+#pragma unroll
+      for (int k = 0; k < NSB; ++k) store_B_item(k, chunk, buf);
     } else {
       const int* ex = xe_lds + chunk * 8;
 #pragma unroll
@@ -382,9 +395,18 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
       const bool stage = !last_chunk || more_tiles;
       const bool next_tile = last_chunk && more_tiles;
       X2_MARK(0);
-      if (stage) {
-        load_B(next_tile ? nn : n, next_tile ? nd0 : d0, next_tile ? nh0 : h0, next_tile ? nw0 : w0, next_tile ? 0 : chunk + 1);
-        load_A(next_tile ? 0 : chunk + 1);
+      // staging steps ride between the MFMAs (one global load / one LDS store per tap pair, see the pair loop): issued as a
+      // burst in front of the chunk, 9 loads and their address arithmetic kept BOTH waves of a SIMD -- and the matrix pipe --
+      // busy for 1.0-2.4 k of a chunk's 8.7 k cycles, and the stores behind the MFMAs cost another 0.6 k (s_memtime stamps,
+      // tools/x2_stamps.py); only the unaligned fp32 path (W % 4 != 0) still stages that way
+      const int s_n = next_tile ? nn : n, s_d0 = next_tile ? nd0 : d0, s_h0 = next_tile ? nh0 : h0, s_w0 = next_tile ? nw0 : w0;
+      const int s_chunk = next_tile ? 0 : chunk + 1, s_on = stage ? 1 : 0;
+      const __amdgpu_buffer_rsrc_t s_xr = dca_rsrc(a.x + (long)s_n * sample, sample * 4);
+      if constexpr (!PIN && !VEC) {
+        if (stage) {
+          load_B(s_n, s_d0, s_h0, s_w0, s_chunk);
+          load_A(s_chunk);
+        }
       }
       const char* ab = a_lds + buf * A_CHUNK + lane * 16;
       const char* bb = b_lds + buf * B_BYTES;
@@ -419,19 +441,31 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
 #pragma unroll
           for (int t = 0; t < 2; ++t)
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][PA[q]], fb[cur][t][PB[q]], acc[t], 0, 0, 0);
+        // this pair's share of the staging (compile-time schedule; p is a constant of the unrolled loop):
+        //   loads:  halo step p (p < NLB), weight word p - LA0: everything is requested by pair 7
+        //   stores: halo step p - SB0 and weight word p - SA0, a few pairs (~0.4 k cycles each) after their loads
+        constexpr int SB0 = PIN ? 6 : 9, SA0 = 10, LA0 = PIN ? 0 : 4;
+        if constexpr (PIN || VEC) {
+          if (p >= LA0 && p - LA0 < KA) load_A_item(p - LA0, s_chunk, s_on);
+          if (p < NLB) load_B_item(p, s_xr, s_d0, s_h0, s_w0, s_chunk, s_on);
+          if (p >= SB0 && p - SB0 < NSB) store_B_item(p - SB0, s_chunk, buf ^ 1);
+          if (p >= SA0 && p - SA0 < KA) store_A_item(p - SA0, buf ^ 1);
+        }
         if (p + 1 < NPAIR) {
 #pragma unroll
           for (int i = 0; i < 6; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            if (i < 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one LDS read (the next pair's fragments)
           }
         }
+        __builtin_amdgcn_sched_barrier(0);     // nothing moves across pairs: the staging steps stay where they are written
       }
       X2_MARK(2);
-      if (stage) {
-        store_B(next_tile ? 0 : chunk + 1, buf ^ 1);
-        store_A(buf ^ 1);
+      if constexpr (!PIN && !VEC) {
+        if (stage) {
+          store_B(s_chunk, buf ^ 1);
+          store_A(buf ^ 1);
+        }
       }
       X2_MARK(3);
       __syncthreads();

@@ -47,11 +47,11 @@ for it in range(3):
     torch.cuda.synchronize()
 ref = torch.nn.functional.conv3d(x, wgt, padding=1)
 print("packed" if packed else "fp32", "stats" if stats else "", "max err vs torch %.2e" % (y - ref).abs().max().item())
-for wv in (0, 7):
-    s = stamps[wv * 768:(wv + 1) * 768].view(96, 8).cpu()
+for slot, wv in enumerate((0, 7)):
+    s = stamps[slot * 768:(slot + 1) * 768].view(96, 8).cpu()
     t0 = int(s[0, 0])
     print(f"wave {wv}: chunk rows (cycles since first mark; s_memtime ticks at 100 MHz x ... printed raw deltas)")
-    for k in range(0, 40):
+    for k in range(0, 16):
         row = [int(v) for v in s[k]]
         if row[0] == 0:
             break
