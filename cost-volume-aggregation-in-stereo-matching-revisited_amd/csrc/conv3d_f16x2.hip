@@ -151,10 +151,10 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
   bool stat_first = true;
   // STATS: per-lane running sums of (y - K) and (y - K)^2 over all tiles of the workgroup (the epilogue-free variants have
   // the 32 registers to spare), reduced over the wave halves once, after the tile loop
-  float st_s[STATS ? 16 : 1], st_q[STATS ? 16 : 1], st_n = 0.f;
+  float st_s[STATS ? 16 : 1], st_q[STATS ? 16 : 1], st_k[STATS ? 16 : 1], st_n = 0.f;   // st_k: the shifts K, in registers
   if constexpr (STATS) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) st_s[r] = st_q[r] = 0.f;
+    for (int r = 0; r < 16; ++r) st_s[r] = st_q[r] = st_k[r] = 0.f;
   }
   float ycm[EPI == 1 ? 16 : 1];          // max |y| this lane has written, per accumulator register = output channel (y_cmax)
 #pragma unroll
@@ -468,7 +468,10 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
         }
       }
       X2_MARK(3);
-      __syncthreads();
+      // the barrier of a tile's last chunk comes AFTER the epilogue: the epilogue touches neither image pair, so the older
+      // wave of a SIMD (which wins the matrix pipe and finishes its 84 MFMAs ~2 k cycles early) stores its results while the
+      // younger one still computes
+      if (!last_chunk) __syncthreads();
       X2_MARK(5);
 #if X2_STAMP
       if (chunk + 1 < NC) ++stamp_k;
@@ -534,10 +537,10 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
         }
         if constexpr (STATS) {
           if (stat_first && t == 0) {   // the wave's first tile: the shift of (half, r) = what lane 0 of the half produced
-            const float kf = fs_half_first(v, half);
-            if ((lane & 31) == 0) fs_slot(stat_w, half, r)[0] = kf;
+            st_k[r] = fs_half_first(v, half);
+            if ((lane & 31) == 0) fs_slot(stat_w, half, r)[0] = st_k[r];     // fs_flush reads it there
           }
-          const float dlt = ok ? v - fs_slot(stat_w, half, r)[0] : 0.f;
+          const float dlt = ok ? v - st_k[r] : 0.f;     // (an LDS read of K per value cost the statistics epilogue ~1 k cycles)
           st_s[r] += dlt;
           st_q[r] = fmaf(dlt, dlt, st_q[r]);
         }
@@ -552,6 +555,7 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
     }
     if constexpr (STATS) stat_first = false;
     X2_MARK(7);
+    __syncthreads();     // (the last chunk's barrier: the next tile's first images are complete, this tile's are free)
 #if X2_STAMP
     ++stamp_k;
 #endif

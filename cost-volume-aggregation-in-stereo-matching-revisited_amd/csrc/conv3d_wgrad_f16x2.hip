@@ -69,7 +69,8 @@ constexpr int XE_TERM = NHROW * 2 * 32 * 4;         // edge dwords: [hrow][side]
 constexpr int Y_TERM = NROW * 2 * 32 * 16;
 constexpr int X_OFF = 0, XE_OFF = NT * X_TERM, Y_OFF = XE_OFF + NT * XE_TERM;
 constexpr int LDS_BYTES_T = Y_OFF + NT * Y_TERM;    // 49152 + 12288 + 16384 = 77824
-constexpr int LDS_BYTES = LDS_BYTES_T > 4 * 7 * 4096 ? LDS_BYTES_T : 4 * 7 * 4096;   // the end-of-kernel reduction reuses the LDS (114688)
+constexpr int LDS_BYTES = 2 * LDS_BYTES_T;           // two tile images (155648); the end-of-kernel reduction reuses them (114688)
+static_assert(LDS_BYTES >= 4 * 7 * 4096 && LDS_BYTES + 128 <= 163840, "LDS budget");
 constexpr int NX_ITEMS = NHROW * 2 * 32, KX = NX_ITEMS / 512;    // 1536 -> 3 per thread (8 floats each)
 constexpr int NE_ITEMS = NHROW * 2 * 32, KE = NE_ITEMS / 512;    // 1536 -> 3 scalars per thread
 constexpr int NY_ITEMS = NROW * 2 * 32, KY = NY_ITEMS / 512;     // 512  -> 1 per thread
@@ -147,62 +148,56 @@ __global__ __launch_bounds__(512) void wgrad3_f16x2_kernel(WX2Args a) {
     n = tile / a.nTD;
     d0 = td * TD; h0 = th * TH; w0 = tw * TW;
   };
-  auto load_tile = [&](int n, int d0, int h0, int w0) __attribute__((always_inline)) {
-    const __amdgpu_buffer_rsrc_t xr = dca_rsrc(a.x + (long)n * xsample, xsample * 4);
-    const __amdgpu_buffer_rsrc_t yr = dca_rsrc(a.dy + (long)n * ysample, ysample * 4);
+  // Staging of a tile, in steps that ride between the MFMAs of the PREVIOUS tile (round 3: the loads issued as one burst
+  // and the split / transpose + LDS stores between two barriers left the matrix pipe idle for a third of a tile):
+  //   load step  s = 0 .. NLOAD-1:  one global load (packed: word s of the thread's 8-voxel unit, then its edge word;
+  //                                 fp32: x quads, x edge voxels, dy quads)
+  //   store step q = 0 .. NSTORE-1: [split /] transpose and LDS stores of a quarter unit (packed) or of one item (fp32)
+  // into the tile image that is not being read: ONE barrier per tile.
+  constexpr int NLOAD = 11, NSTORE = 7;
+  auto load_step = [&](int s, __amdgpu_buffer_rsrc_t xr, __amdgpu_buffer_rsrc_t yr, int d0, int h0, int w0, int on) __attribute__((always_inline)) {
     if constexpr (XP) {
-      if (tid < NXU) {    // unit (term, hrow, k half, group): words of voxels w0 + 8 hf + 0..7; + the edge word of (term, hrow, side, group)
+      if (s < 9 && tid < NXU) {    // unit (term, hrow, k half, group): words of voxels w0 + 8 hf + 0..7; + the edge word of (term, hrow, side, group)
         const int g = tid & 3, hf = (tid >> 2) & 1, hrow = (tid >> 3) % NHROW, term = tid / (8 * NHROW);
         const int d = d0 - 1 + hrow / HH, h = h0 - 1 + hrow % HH, w = w0 + 8 * hf, cg = (cx0 >> 3) + g;
-        const int ok = (int)(cg * 8 < a.Cx) & (int)((unsigned)d < (unsigned)a.D) & (int)((unsigned)h < (unsigned)a.H);
+        const int ok = (int)(cg * 8 < a.Cx) & (int)((unsigned)d < (unsigned)a.D) & (int)((unsigned)h < (unsigned)a.H) & on;
         const int off = term * (a.Cx * cstride * 2) + (cg * cstride + (d * a.H + h) * a.W + w) * 16;
-#pragma unroll
-        for (int v = 0; v < 8; ++v)
-          pu[v] = __builtin_bit_cast(u32x4v, dca_bload4(xr, off + 16 * v, ok & (int)(w + v < a.W)));
-        const int we = hf ? w0 + TW : w0 - 1;     // side = hf
-        pe = __builtin_bit_cast(u32x4v, dca_bload4(xr, off + (we - w) * 16, ok & (int)((unsigned)we < (unsigned)a.W)));
+        if (s < 8) {
+          pu[s] = __builtin_bit_cast(u32x4v, dca_bload4(xr, off + 16 * s, ok & (int)(w + s < a.W)));
+        } else {
+          const int we = hf ? w0 + TW : w0 - 1;     // side = hf
+          pe = __builtin_bit_cast(u32x4v, dca_bload4(xr, off + (we - w) * 16, ok & (int)((unsigned)we < (unsigned)a.W)));
+        }
+      }
+    } else {
+      if (s < 6) {
+        const int k = s >> 1, it = tid + 512 * k, c = it & 31, hf = (it >> 5) & 1, hrow = it >> 6;
+        const int d = d0 - 1 + hrow / HH, h = h0 - 1 + hrow % HH, w = w0 + 8 * hf + 4 * (s & 1);
+        const int ok = (int)(cx0 + c < a.Cx) & (int)((unsigned)d < (unsigned)a.D) & (int)((unsigned)h < (unsigned)a.H) & on;
+        rx[k][s & 1] = dca_bload4(xr, ((cx0 + c) * cstride + (d * a.H + h) * a.W + w) * 4, ok & (int)(w + 3 < a.W));   // W % 4 == 0
+      } else if (s < 9) {
+        const int k = s - 6, it = tid + 512 * k, c = it & 31, side = (it >> 5) & 1, hrow = it >> 6;
+        const int d = d0 - 1 + hrow / HH, h = h0 - 1 + hrow % HH, w = side ? w0 + TW : w0 - 1;
+        const int ok = (int)(cx0 + c < a.Cx) & (int)((unsigned)d < (unsigned)a.D) & (int)((unsigned)h < (unsigned)a.H) &
+                       (int)((unsigned)w < (unsigned)a.W) & on;
+        re[k] = dca_bload1(xr, ((cx0 + c) * cstride + (d * a.H + h) * a.W + w) * 4, ok);
       }
     }
     if constexpr (YP) {
-      if (tid >= NXU) {
+      if (s < 8 && tid >= NXU) {
         const int u = tid - NXU, g = u & 3, hf = (u >> 2) & 1, row = (u >> 3) % NROW, term = u / (8 * NROW);
         const int d = d0 + row / TH, h = h0 + row % TH, w = w0 + 8 * hf, cg = (cy0 >> 3) + g;
-        const int ok = (int)(cg * 8 < a.Cy) & (int)(d < a.D) & (int)(h < a.H);
+        const int ok = (int)(cg * 8 < a.Cy) & (int)(d < a.D) & (int)(h < a.H) & on;
         const int off = term * (a.Cy * cstride * 2) + (cg * cstride + (d * a.H + h) * a.W + w) * 16;
-#pragma unroll
-        for (int v = 0; v < 8; ++v)
-          pu[v] = __builtin_bit_cast(u32x4v, dca_bload4(yr, off + 16 * v, ok & (int)(w + v < a.W)));
+        pu[s] = __builtin_bit_cast(u32x4v, dca_bload4(yr, off + 16 * s, ok & (int)(w + s < a.W)));
       }
-    }
-    if constexpr (!XP) {
-#pragma unroll
-    for (int k = 0; k < KX; ++k) {
-      const int it = tid + 512 * k, c = it & 31, hf = (it >> 5) & 1, hrow = it >> 6;
-      const int d = d0 - 1 + hrow / HH, h = h0 - 1 + hrow % HH, w = w0 + 8 * hf;
-      const int ok = (int)(cx0 + c < a.Cx) & (int)((unsigned)d < (unsigned)a.D) & (int)((unsigned)h < (unsigned)a.H);
-      const int off = ((cx0 + c) * cstride + (d * a.H + h) * a.W + w) * 4;
-      rx[k][0] = dca_bload4(xr, off, ok & (int)(w + 3 < a.W));       // W % 4 == 0: a quad is inside or outside
-      rx[k][1] = dca_bload4(xr, off + 16, ok & (int)(w + 7 < a.W));
-    }
-#pragma unroll
-    for (int k = 0; k < KE; ++k) {
-      const int it = tid + 512 * k, c = it & 31, side = (it >> 5) & 1, hrow = it >> 6;
-      const int d = d0 - 1 + hrow / HH, h = h0 - 1 + hrow % HH, w = side ? w0 + TW : w0 - 1;
-      const int ok = (int)(cx0 + c < a.Cx) & (int)((unsigned)d < (unsigned)a.D) & (int)((unsigned)h < (unsigned)a.H) &
-                     (int)((unsigned)w < (unsigned)a.W);
-      re[k] = dca_bload1(xr, ((cx0 + c) * cstride + (d * a.H + h) * a.W + w) * 4, ok);
-    }
-    }
-    if constexpr (!YP) {
-#pragma unroll
-    for (int k = 0; k < KY; ++k) {
-      const int it = tid + 512 * k, c = it & 31, hf = (it >> 5) & 1, row = it >> 6;
-      const int d = d0 + row / TH, h = h0 + row % TH, w = w0 + 8 * hf;
-      const int ok = (int)(cy0 + c < a.Cy) & (int)(d < a.D) & (int)(h < a.H);
-      const int off = ((cy0 + c) * cstride + (d * a.H + h) * a.W + w) * 4;
-      ry[k][0] = dca_bload4(yr, off, ok & (int)(w + 3 < a.W));
-      ry[k][1] = dca_bload4(yr, off + 16, ok & (int)(w + 7 < a.W));
-    }
+    } else {
+      if (s >= 9) {
+        const int it = tid, c = it & 31, hf = (it >> 5) & 1, row = it >> 6;
+        const int d = d0 + row / TH, h = h0 + row % TH, w = w0 + 8 * hf + 4 * (s - 9);
+        const int ok = (int)(cy0 + c < a.Cy) & (int)(d < a.D) & (int)(h < a.H) & on;
+        ry[0][s - 9] = dca_bload4(yr, ((cy0 + c) * cstride + (d * a.H + h) * a.W + w) * 4, ok & (int)(w + 3 < a.W));
+      }
     }
   };
   auto split_store8 = [&](const float4& p, const float4& q, int sc, char* base, int term_stride, int off) __attribute__((always_inline)) {
@@ -217,80 +212,76 @@ __global__ __launch_bounds__(512) void wgrad3_f16x2_kernel(WX2Args a) {
     *(f16x8*)(base + off) = hv;
     *(f16x8*)(base + term_stride + off) = lv;
   };
-  auto store_tile = [&]() __attribute__((always_inline)) {
+  // channels 2q, 2q+1 of the unit in pu[]: the 8 voxels of each as one LDS word
+  auto transpose_store = [&](int q, char* dst) __attribute__((always_inline)) {
+    u32x4v lo, hi;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      lo[i] = __builtin_amdgcn_perm(pu[2 * i + 1][q], pu[2 * i][q], 0x05040100u);       // low halves: channel 2q
+      hi[i] = __builtin_amdgcn_perm(pu[2 * i + 1][q], pu[2 * i][q], 0x07060302u);       // high halves: channel 2q+1
+    }
+    *(u32x4v*)(dst + (2 * q) * 16) = lo;
+    *(u32x4v*)(dst + (2 * q + 1) * 16) = hi;
+  };
+  auto store_step = [&](int q, char* img) __attribute__((always_inline)) {
     if constexpr (XP) {
       if (tid < NXU) {
         const int g = tid & 3, hf = (tid >> 2) & 1, hrow = (tid >> 3) % NHROW, term = tid / (8 * NHROW);
-        u32x4v o[8];
-        transpose8x8(pu, o);
-        char* dst = smem + X_OFF + term * X_TERM + ((hrow * 2 + hf) * 32 + g * 8) * 16;      // [hrow][k half][ci][8 voxels]
+        if (q < 4) {
+          transpose_store(q, img + X_OFF + term * X_TERM + ((hrow * 2 + hf) * 32 + g * 8) * 16);      // [hrow][k half][ci][8 voxels]
+        } else if (q == 4) {
+          // edge image [hrow][side][ci] dwords: left edge (side 0) in the HIGH half, right edge (side 1) in the LOW half
+          u32x4v e0, e1;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) *(u32x4v*)(dst + c * 16) = o[c];
-        // edge image [hrow][side][ci] dwords: left edge (side 0) in the HIGH half, right edge (side 1) in the LOW half
-        u32x4v e0, e1;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          const unsigned lo = pe[d] & 0xffffu, hi = pe[d] >> 16;      // channels 2d, 2d+1 of the group
-          const unsigned a0 = hf ? lo : lo << 16, a1 = hf ? hi : hi << 16;
-          if (d < 2) { e0[2 * d] = a0; e0[2 * d + 1] = a1; } else { e1[2 * d - 4] = a0; e1[2 * d - 3] = a1; }
+          for (int d = 0; d < 4; ++d) {
+            const unsigned lo = pe[d] & 0xffffu, hi = pe[d] >> 16;      // channels 2d, 2d+1 of the group
+            const unsigned a0 = hf ? lo : lo << 16, a1 = hf ? hi : hi << 16;
+            if (d < 2) { e0[2 * d] = a0; e0[2 * d + 1] = a1; } else { e1[2 * d - 4] = a0; e1[2 * d - 3] = a1; }
+          }
+          char* de = img + XE_OFF + term * XE_TERM + ((hrow * 2 + hf) * 32 + g * 8) * 4;
+          *(u32x4v*)de = e0;
+          *(u32x4v*)(de + 16) = e1;
         }
-        char* de = smem + XE_OFF + term * XE_TERM + ((hrow * 2 + hf) * 32 + g * 8) * 4;
-        *(u32x4v*)de = e0;
-        *(u32x4v*)(de + 16) = e1;
       }
     } else {
-#pragma unroll
-      for (int k = 0; k < KX; ++k) split_store8(rx[k][0], rx[k][1], xe_t, smem + X_OFF, X_TERM, (tid + 512 * k) * 16);
-#pragma unroll
-      for (int k = 0; k < KE; ++k) {
-        const int it = tid + 512 * k, side = (it >> 5) & 1;
+      if (q < 3) {
+        split_store8(rx[q][0], rx[q][1], xe_t, img + X_OFF, X_TERM, (tid + 512 * q) * 16);
+      } else if (q < 6) {
+        const int k = q - 3, it = tid + 512 * k, side = (it >> 5) & 1;
         _Float16 h, l;
         split2(re[k], xe_t, h, l);
         // left edge (side 0) sits in the HIGH half of its dword, right edge (side 1) in the LOW half (see shifts below)
         const unsigned sh = side ? 0 : 16;
-        *(unsigned*)(smem + XE_OFF + it * 4) = (unsigned)__builtin_bit_cast(unsigned short, h) << sh;
-        *(unsigned*)(smem + XE_OFF + XE_TERM + it * 4) = (unsigned)__builtin_bit_cast(unsigned short, l) << sh;
+        *(unsigned*)(img + XE_OFF + it * 4) = (unsigned)__builtin_bit_cast(unsigned short, h) << sh;
+        *(unsigned*)(img + XE_OFF + XE_TERM + it * 4) = (unsigned)__builtin_bit_cast(unsigned short, l) << sh;
       }
     }
     if constexpr (YP) {
-      if (tid >= NXU) {
+      if (q < 4 && tid >= NXU) {
         const int u = tid - NXU, g = u & 3, hf = (u >> 2) & 1, row = (u >> 3) % NROW, term = u / (8 * NROW);
-        u32x4v o[8];
-        transpose8x8(pu, o);
-        char* dst = smem + Y_OFF + term * Y_TERM + ((row * 2 + hf) * 32 + g * 8) * 16;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) *(u32x4v*)(dst + c * 16) = o[c];
+        transpose_store(q, img + Y_OFF + term * Y_TERM + ((row * 2 + hf) * 32 + g * 8) * 16);
       }
     } else {
-#pragma unroll
-      for (int k = 0; k < KY; ++k) split_store8(ry[k][0], ry[k][1], ye_t, smem + Y_OFF, Y_TERM, (tid + 512 * k) * 16);
+      if (q == 6) split_store8(ry[0][0], ry[0][1], ye_t, img + Y_OFF, Y_TERM, tid * 16);
     }
   };
 
-  // The MFMA phase of one tile for tap group WQ (taps 7*WQ .. 7*WQ+6, < 27).  The next tile's global loads are issued
-  // BEHIND the first K-step's MFMAs: in front of the phase the address arithmetic and the memory pipe's back-pressure of
-  // 11 load instructions per thread kept all eight waves -- and the matrix pipe -- busy for 1600-1900 of a tile's 18.9 k
-  // cycles (s_memtime stamps, tools/wx3_stamps.py).
-  auto mfma_tile = [&](auto WQC, bool more, int next_tile) __attribute__((always_inline)) {
+  // The MFMA phase of one tile for tap group WQ (taps 7*WQ .. 7*WQ+6, < 27), reading tile image `img`; the next tile's
+  // staging steps follow the MFMAs of a tap at compile-time positions: loads behind taps 0 .. 10 of the wave's 24-28 (tap,
+  // K-step) slots, stores into `nimg` behind slots 16 .. 22.
+  auto mfma_tile = [&](auto WQC, const char* img, char* nimg, int on, __amdgpu_buffer_rsrc_t xr, __amdgpu_buffer_rsrc_t yr,
+                       int nd0, int nh0, int nw0) __attribute__((always_inline)) {
     constexpr int WQ = decltype(WQC)::value;
-#if WX2_G8
-    constexpr int TAP0 = 27 * WQ / 8, TAP1 = 27 * (WQ + 1) / 8;
-#else
     constexpr int TAP0 = 7 * WQ, TAP1 = (TAP0 + 7 < 27) ? TAP0 + 7 : 27;
-#endif
     constexpr int R0 = TAP0 / 3, R1 = (TAP1 - 1) / 3;  // (kd, kh) rows this wave touches
-#pragma unroll 1
+    int slot = 0;    // a compile-time constant after unrolling
+#pragma unroll
     for (int i = 0; i < NROW / NGRP; ++i) {
-      if (WX2_LOADS_IN && i == 1 && more) {
-        int nn, nd0, nh0, nw0;
-        decode(next_tile, nn, nd0, nh0, nw0);
-        load_tile(nn, nd0, nh0, nw0);
-      }
       const int row = grp * (NROW / NGRP) + i, dl = row / TH, hl = row % TH;
       f16x8 ay[NT];
 #pragma unroll
       for (int term = 0; term < NT; ++term)
-        ay[term] = *(const f16x8*)(smem + Y_OFF + term * Y_TERM + ((row * 2 + half) * 32 + l31) * 16);
+        ay[term] = *(const f16x8*)(img + Y_OFF + term * Y_TERM + ((row * 2 + half) * 32 + l31) * 16);
 #pragma unroll
       for (int rr = R0; rr <= R1; ++rr) {
         const int kd = rr / 3, kh = rr % 3;
@@ -299,8 +290,8 @@ __global__ __launch_bounds__(512) void wgrad3_f16x2_kernel(WX2Args a) {
         unsigned e[NT];
 #pragma unroll
         for (int term = 0; term < NT; ++term) {
-          g[term] = *(const u32x4v*)(smem + X_OFF + term * X_TERM + ((hrow * 2 + half) * 32 + l31) * 16);
-          e[term] = *(const unsigned*)(smem + XE_OFF + term * XE_TERM + ((hrow * 2 + half) * 32 + l31) * 4);
+          g[term] = *(const u32x4v*)(img + X_OFF + term * X_TERM + ((hrow * 2 + half) * 32 + l31) * 16);
+          e[term] = *(const unsigned*)(img + XE_OFF + term * XE_TERM + ((hrow * 2 + half) * 32 + l31) * 4);
         }
         // fragments for kw = 0 (g itself), kw = -1 (s[0..3]) and kw = +1 (s[1..4])
         u32x4v fm[NT], fp[NT];
@@ -330,57 +321,48 @@ __global__ __launch_bounds__(512) void wgrad3_f16x2_kernel(WX2Args a) {
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ay[0], bx[1], acc[j], 0, 0, 0);
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ay[1], bx[0], acc[j], 0, 0, 0);
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ay[0], bx[0], acc[j], 0, 0, 0);
+          if (slot < NLOAD) load_step(slot, xr, yr, nd0, nh0, nw0, on);
+          if (slot >= 16 && slot - 16 < NSTORE) store_step(slot - 16, nimg);
+          ++slot;
         }
+        __builtin_amdgcn_sched_barrier(0);     // the staging steps stay behind their taps; no fragment reads hoisted across rows
       }
     }
   };
 
-#if WX2_STAMP
-  unsigned long long* stamps = (unsigned long long*)(a.part + (long)gridDim.x * gridDim.y * 27 * 1024);
-  const bool stamp_on = blockIdx.x == 0 && blockIdx.y == 0 && grp == 0 && (wq == 0 || wq == 3);
-  int stamp_k = 0;
-#endif
   if (t_begin < t_end) {
     int n, d0, h0, w0;
     decode(t_begin, n, d0, h0, w0);
-    load_tile(n, d0, h0, w0);
-    store_tile();
+    {
+      const __amdgpu_buffer_rsrc_t xr = dca_rsrc(a.x + (long)n * xsample, xsample * 4);
+      const __amdgpu_buffer_rsrc_t yr = dca_rsrc(a.dy + (long)n * ysample, ysample * 4);
+#pragma unroll
+      for (int s2 = 0; s2 < NLOAD; ++s2) load_step(s2, xr, yr, d0, h0, w0, 1);
+#pragma unroll
+      for (int q = 0; q < NSTORE; ++q) store_step(q, smem);
+    }
     __syncthreads();
+    int buf = 0;
 #pragma unroll 1
-    for (int tile = t_begin; tile < t_end; tile += t_step) {
+    for (int tile = t_begin; tile < t_end; tile += t_step, buf ^= 1) {
       const bool more = tile + t_step < t_end;
-      WX2_MARK(0);
-      if (more && !WX2_LOADS_IN) {
-        decode(tile + t_step, n, d0, h0, w0);
-        load_tile(n, d0, h0, w0);
-      }
-      WX2_MARK(1);
+      int nn = n, nd0 = d0, nh0 = h0, nw0 = w0;
+      if (more) decode(tile + t_step, nn, nd0, nh0, nw0);
+      const __amdgpu_buffer_rsrc_t xr = dca_rsrc(a.x + (long)nn * xsample, xsample * 4);
+      const __amdgpu_buffer_rsrc_t yr = dca_rsrc(a.dy + (long)nn * ysample, ysample * 4);
+      const char* img = smem + buf * LDS_BYTES_T;
+      char* nimg = smem + (buf ^ 1) * LDS_BYTES_T;
+      const int on = more ? 1 : 0;
       switch (wq) {
-        case 0: mfma_tile(std::integral_constant<int, 0>{}, more, tile + t_step); break;
-        case 1: mfma_tile(std::integral_constant<int, 1>{}, more, tile + t_step); break;
-        case 2: mfma_tile(std::integral_constant<int, 2>{}, more, tile + t_step); break;
-#if WX2_G8
-        case 3: mfma_tile(std::integral_constant<int, 3>{}, more, tile + t_step); break;
-        case 4: mfma_tile(std::integral_constant<int, 4>{}, more, tile + t_step); break;
-        case 5: mfma_tile(std::integral_constant<int, 5>{}, more, tile + t_step); break;
-        case 6: mfma_tile(std::integral_constant<int, 6>{}, more, tile + t_step); break;
-        default: mfma_tile(std::integral_constant<int, 7>{}, more, tile + t_step); break;
-#else
-        default: mfma_tile(std::integral_constant<int, 3>{}, more, tile + t_step); break;
-#endif
+        case 0: mfma_tile(std::integral_constant<int, 0>{}, img, nimg, on, xr, yr, nd0, nh0, nw0); break;
+        case 1: mfma_tile(std::integral_constant<int, 1>{}, img, nimg, on, xr, yr, nd0, nh0, nw0); break;
+        case 2: mfma_tile(std::integral_constant<int, 2>{}, img, nimg, on, xr, yr, nd0, nh0, nw0); break;
+        default: mfma_tile(std::integral_constant<int, 3>{}, img, nimg, on, xr, yr, nd0, nh0, nw0); break;
       }
-      WX2_MARK(2);
-      __syncthreads();  // every wave is done reading this tile
-      WX2_MARK(3);
-      if (more) store_tile();
-      WX2_MARK(4);
-      __syncthreads();
-      WX2_MARK(5);
-#if WX2_STAMP
-      ++stamp_k;
-#endif
+      __syncthreads();  // every wave is done reading this tile's image and writing the next one's
     }
   }
+
 
   // scale-back: entry (co, ci) by 2^-(yexps[co] + xexps[ci]); ci = this lane's column, co = 16 rows per lane
   __syncthreads();
