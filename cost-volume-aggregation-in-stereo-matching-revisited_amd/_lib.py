@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(HERE, "libdca_hip.so")
 
 _p, _i, _l, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double
 
-ABI_VERSION = 13  # == DCA_ABI_VERSION of include/dca_hip.h
+ABI_VERSION = 14  # == DCA_ABI_VERSION of include/dca_hip.h
 
 # name -> (restype, argtypes); mirrors include/dca_hip.h one to one
 SIGNATURES = {
@@ -33,7 +33,7 @@ SIGNATURES = {
     "dca_conv3d_x3_forward": (_i, [_p] * 7 + [_f] + [_i] * 6 + [_p]),
     "dca_conv3d_x3_stats_chunks": (_l, [_i] * 5),
     "dca_conv3d_x3_forward_stats": (_i, [_p] * 4 + [_i] * 6 + [_p]),
-    "dca_bn_finalize_centered": (_i, [_p, _i, _p, _p, _p, _p, _f, _f, _p, _p, _i, _p]),
+    "dca_bn_finalize_centered": (_i, [_p, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _i, _p, _i, _i, _p]),
     "dca_conv1_x3_stats_chunks": (_l, [_i, _l]),
     "dca_conv1_x3_forward_stats": (_i, [_p] * 5 + [_i] * 6 + [_l, _p]),
     "dca_deconv3d_x3_stats_chunks": (_l, [_i] * 4),
@@ -59,10 +59,10 @@ SIGNATURES = {
     "dca_bn_num_chunks": (_i, [_i, _l]),
     "dca_bn_pack_chunks": (_i, [_i, _l]),
     "dca_cmax_exps": (_i, [_p, _i, _i, _p, _p]),
-    "dca_bn_apply_pack": (_i, [_p, _p, _p, _p, _i, _i, _l, _f, _p, _p]),
+    "dca_bn_apply_pack": (_i, [_p, _p, _p, _p, _i, _i, _l, _f, _p, _p, _p, _p, _p, _p]),
     "dca_bn_backward_pack": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _l, _f, _i, _p]),
     "dca_bn_stats": (_i, [_p, _p, _i, _i, _l, _p]),
-    "dca_bn_finalize": (_i, [_p, _i, _d, _p, _p, _p, _p, _f, _f, _i, _p, _p, _i, _p]),
+    "dca_bn_finalize": (_i, [_p, _i, _d, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _i, _p, _i, _i, _p]),
     "dca_bn_apply": (_i, [_p, _p, _p, _p, _p, _i, _i, _l, _f, _p, _p, _p]),
     "dca_bn_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _l, _f, _i, _p, _p]),
     "dca_avgpool3d_fwd": (_i, [_p, _p, _l, _i, _i, _i, _p]),

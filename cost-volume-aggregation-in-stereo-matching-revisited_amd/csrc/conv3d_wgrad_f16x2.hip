@@ -151,12 +151,14 @@ __global__ __launch_bounds__(512) void wgrad3_f16x2_kernel(WX2Args a) {
     n = tile / a.nTD;
     d0 = td * TD; h0 = th * TH; w0 = tw * TW;
   };
-  auto load_tile = [&](int n, int d0, int h0, int w0) __attribute__((always_inline)) {
+  // part 0: the first half of the x loads (packed: words 0-3; fp32: the quad), part 1: the rest of x and dy; -1: everything
+  auto load_tile = [&](int n, int d0, int h0, int w0, int part = -1) __attribute__((always_inline)) {
     const __amdgpu_buffer_rsrc_t xr = dca_rsrc(a.x + (long)n * xsample, xsample * 4);
     const __amdgpu_buffer_rsrc_t yr = dca_rsrc(a.dy + (long)n * ysample, ysample * 4);
     if constexpr (XP) {
 #pragma unroll
       for (int k = 0; k < KXW; ++k) {
+        if ((part == 0 && k >= 4) || (part == 1 && k < 4)) continue;
         int crd = xcrd[k];
         asm volatile("" : "+v"(crd));
         const int d = d0 - 1 + (crd & 15), h = h0 - 1 + ((crd >> 4) & 15), w = w0 - 1 + ((crd >> 8) & 255);
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(512) void wgrad3_f16x2_kernel(WX2Args a) {
         pw[k] = dca_bload4(xr, term * (a.Cx * cstride * 2) + (g * cstride + (d * a.H + h) * a.W + w) * 16, ok);
       }
     } else {
-      if (tid < NXQ) {
+      if (part != 1 && tid < NXQ) {
         const int cg = tid & 3, quad = (tid >> 2) & 3, hrow = tid >> 4;
         const int d = d0 - 1 + hrow / HH, h = h0 - 1 + hrow % HH, w = w0 + 4 * quad, c0 = cx0 + cg * 8;
         const int ok = (int)((unsigned)d < (unsigned)a.D) & (int)((unsigned)h < (unsigned)a.H) & (int)(w + 3 < a.W);   // W % 4 == 0
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(512) void wgrad3_f16x2_kernel(WX2Args a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) rq[j] = dca_bload4(xr, off + j * cstride * 4, ok & (int)(c0 + j < a.Cx));
       }
-      if (tid < NXE) {
+      if (part != 0 && tid < NXE) {
         const int cg = tid & 3, side = (tid >> 2) & 1, hrow = tid >> 3;
         const int d = d0 - 1 + hrow / HH, h = h0 - 1 + hrow % HH, w = side ? w0 + TW : w0 - 1, c0 = cx0 + cg * 8;
         const int ok = (int)((unsigned)d < (unsigned)a.D) & (int)((unsigned)h < (unsigned)a.H) & (int)((unsigned)w < (unsigned)a.W);
@@ -183,6 +185,7 @@ __global__ __launch_bounds__(512) void wgrad3_f16x2_kernel(WX2Args a) {
         for (int j = 0; j < 8; ++j) re[j] = dca_bload1(xr, off + j * cstride * 4, ok & (int)(c0 + j < a.Cx));
       }
     }
+    if (part == 0) return;
     if constexpr (YP) {
 #pragma unroll
       for (int k = 0; k < KYW; ++k) {
@@ -268,10 +271,10 @@ __global__ __launch_bounds__(512) void wgrad3_f16x2_kernel(WX2Args a) {
     constexpr int TAP0 = 7 * WQ, TAP1 = (TAP0 + 7 < 27) ? TAP0 + 7 : 27, NTAP = TAP1 - TAP0;
 #pragma unroll 1
     for (int i = 0; i < TH; ++i) {
-      if (i == 1 && more) {
+      if ((i == 1 || i == 2) && more) {     // in two portions: one burst of up to 18 loads stalls the memory pipe -- and the MFMAs
         int nn, nd0, nh0, nw0;
         decode(next_tile, nn, nd0, nh0, nw0);
-        load_tile(nn, nd0, nh0, nw0);
+        load_tile(nn, nd0, nh0, nw0, i - 1);
       }
       // K-step (d = d0 + grp, h = h0 + i): dy row grp*TH + i; x halo rows (grp + kd, i + kh)
       const char* yb = smem + Y_OFF + ((grp * TH + i) * TW) * VB + lane_off;

@@ -54,8 +54,21 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
 // |beta| whatever the data -- known BEFORE z is written, which is what lets bn_apply_pack_kernel write the packed operand
 // format in one pass.  The bound is loose (a Gaussian's maximum over 6e6 samples is ~5.3 sigma, the bound 2500): typical
 // values land ~2^9 below the [2^14, 2^15) target, inside the 18 binades over which the two f16 terms keep all 22 bits.
-__device__ __forceinline__ int bn_bound_exp(float gamma, float beta, double count) {
-  const float b = (fabsf(gamma) * sqrtf((float)count) + fabsf(beta)) * 1.0001f;
+// With residuals z = act(BN(y) + res_pre) + res_post the bound grows by the residual channels' maxima (their producers'
+// per-channel slots, dca_common.h).  Wave-wide call (the slots are reduced over the lanes); the result is valid in lane 0.
+__device__ __forceinline__ int bn_bound_exp(float gamma, float beta, double count, int c, const unsigned* rp_slots, int rp_n,
+                                            const unsigned* rq_slots, int rq_n) {
+  unsigned a = 0, b2 = 0;
+  const int lane = threadIdx.x & 63;
+  if (rp_slots) for (int i = lane; i < rp_n; i += 64) { const unsigned u = rp_slots[(long)c * DCA_AMAX_CSLOTS + i]; a = a > u ? a : u; }
+  if (rq_slots) for (int i = lane; i < rq_n; i += 64) { const unsigned u = rq_slots[(long)c * DCA_AMAX_CSLOTS + i]; b2 = b2 > u ? b2 : u; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned u = (unsigned)__shfl_xor((int)a, o, 64), w = (unsigned)__shfl_xor((int)b2, o, 64);
+    a = a > u ? a : u;
+    b2 = b2 > w ? b2 : w;
+  }
+  const float b = (fabsf(gamma) * sqrtf((float)count) + fabsf(beta) + __uint_as_float(a) + __uint_as_float(b2)) * 1.0001f;
   return x2_scale_exp(__float_as_uint(b));
 }
 
@@ -64,7 +77,9 @@ __device__ __forceinline__ int bn_bound_exp(float gamma, float beta, double coun
 __global__ __launch_bounds__(64) void bn_finalize_kernel(const double* __restrict__ part, int nchunk, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
-                                   float eps, int training, float* __restrict__ stats, int* __restrict__ zexps, int C) {
+                                   float eps, int training, float* __restrict__ stats, int* __restrict__ zexps,
+                                   const unsigned* __restrict__ rp_slots, int rp_n, const unsigned* __restrict__ rq_slots,
+                                   int rq_n, int C) {
   const int c = blockIdx.x, lane = threadIdx.x;   // one wave per channel; lanes stride over the chunk partials
   float mean, var;
   if (training) {
@@ -90,14 +105,15 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const double* __restric
     mean = running_mean[c];
     var = running_var[c];
   }
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const int ze = zexps ? bn_bound_exp(g, b, count, c, rp_slots, rp_n, rq_slots, rq_n) : 0;
   if (lane != 0) return;
   const float invstd = 1.0f / sqrtf(var + eps);
-  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
   stats[c] = mean;
   stats[C + c] = invstd;
   stats[2 * C + c] = g * invstd;
   stats[3 * C + c] = b - mean * g * invstd;
-  if (zexps) zexps[c] = bn_bound_exp(g, b, count);
+  if (zexps) zexps[c] = ze;
 }
 
 // Training-mode finalize for the statistics the convolution kernels emit themselves (dca_*_forward_stats): partial i of
@@ -107,7 +123,9 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const double* __restric
 __global__ __launch_bounds__(64) void bn_finalize_centered_kernel(const double* __restrict__ part, int nchunk,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
-                                   float eps, float* __restrict__ stats, int* __restrict__ zexps, int C) {
+                                   float eps, float* __restrict__ stats, int* __restrict__ zexps,
+                                   const unsigned* __restrict__ rp_slots, int rp_n, const unsigned* __restrict__ rq_slots,
+                                   int rq_n, int C) {
   const int c = blockIdx.x, lane = threadIdx.x;
   const double* p = part + (long)c * nchunk * 4;
   const double kref = p[0];
@@ -122,6 +140,8 @@ __global__ __launch_bounds__(64) void bn_finalize_centered_kernel(const double* 
   n = wave_sum_d(n);
   s = wave_sum_d(s);
   q = wave_sum_d(q);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const int ze = zexps ? bn_bound_exp(g, b, n, c, rp_slots, rp_n, rq_slots, rq_n) : 0;
   if (lane != 0) return;
   const double ms = s / n;
   double v = q / n - ms * ms;
@@ -133,12 +153,11 @@ __global__ __launch_bounds__(64) void bn_finalize_centered_kernel(const double* 
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
   }
   const float invstd = 1.0f / sqrtf(var + eps);
-  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
   stats[c] = mean;
   stats[C + c] = invstd;
   stats[2 * C + c] = g * invstd;
   stats[3 * C + c] = b - mean * g * invstd;
-  if (zexps) zexps[c] = bn_bound_exp(g, b, n);
+  if (zexps) zexps[c] = ze;
 }
 
 // The f16x2 convolution kernels scale every operand CHANNEL by a power of two taken from the channel's max |.|
@@ -202,13 +221,17 @@ typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 // convolution that consumes it: block (ch, cg) = chunk ch of the 8-channel group cg, all samples; a lane takes ONE voxel and
 // its 8 channels (eight 4-byte loads, each 256 contiguous bytes per wave; two 16-byte stores, 1 KB contiguous per wave).
 // stats == null: identity (plain packing of an fp32 tensor, dca_pack_x2).
+// res_pre / res_post / zf (may be null): the residual adds of bn_apply_kernel and a second, fp32, copy of z for readers
+// other than the f16x2 convolution.
 __global__ __launch_bounds__(256) void bn_apply_pack_kernel(const float* __restrict__ y, const float* __restrict__ stats,
                                                             const int* __restrict__ zexps, char* __restrict__ zp, int N,
                                                             int C, long S, long chunk_len, float slope,
-                                                            unsigned* __restrict__ ymax) {
+                                                            unsigned* __restrict__ ymax, const float* __restrict__ res_pre,
+                                                            const float* __restrict__ res_post, float* __restrict__ zf,
+                                                            unsigned* __restrict__ zmax) {
   const int cg = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
   const long s0 = ch * chunk_len, s1 = min(S, s0 + chunk_len);
-  float mean[8], sc[8], sh[8], ym[8];
+  float mean[8], sc[8], sh[8], ym[8], zm[8];
   int ex[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -217,21 +240,28 @@ __global__ __launch_bounds__(256) void bn_apply_pack_kernel(const float* __restr
     sc[j] = stats ? stats[2 * C + c] : 1.f;
     sh[j] = stats ? stats[3 * C + c] : 0.f;
     ex[j] = dca_coherent_loadi(zexps + c);
-    ym[j] = 0.f;
+    ym[j] = zm[j] = 0.f;
   }
   const long tb = px2_term_bytes(C, S);
   for (int n = 0; n < N; ++n) {
     const float* yb = y + ((long)n * C + cg * 8) * S;
     char* zb = zp + (long)n * 2 * tb + (long)cg * S * 16;
+    const long cb = ((long)n * C + cg * 8) * S;
     for (long i = s0 + tid; i < s1; i += 256) {
-      float v[8];
+      float v[8], rp[8], rq[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = yb[j * S + i];
+      for (int j = 0; j < 8; ++j) {
+        v[j] = yb[j * S + i];
+        rp[j] = res_pre ? res_pre[cb + j * S + i] : 0.f;
+        rq[j] = res_post ? res_post[cb + j * S + i] : 0.f;
+      }
       u16x8 hv, lv;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         ym[j] = fmaxf(ym[j], fabsf(v[j] - mean[j]));
-        const float zz = act_apply(v[j] * sc[j] + sh[j], slope);
+        const float zz = act_apply(v[j] * sc[j] + sh[j] + rp[j], slope) + rq[j];
+        if (zf) zf[cb + j * S + i] = zz;
+        zm[j] = fmaxf(zm[j], fabsf(zz));
         unsigned short h, l;
         px2_split(zz, ex[j], h, l);
         hv[j] = h; lv[j] = l;
@@ -243,6 +273,10 @@ __global__ __launch_bounds__(256) void bn_apply_pack_kernel(const float* __restr
   if (ymax) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) dca_cmax_put(ym[j], ymax + (long)(cg * 8 + j) * DCA_AMAX_CSLOTS + ch);
+  }
+  if (zmax) {     // per-channel max |z| for the readers of the fp32 copy (residual bounds, f16x2 operand scales)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dca_cmax_put(zm[j], zmax + (long)(cg * 8 + j) * DCA_AMAX_CSLOTS + ch);
   }
 }
 
@@ -888,20 +922,27 @@ extern "C" int dca_bn_stats(const float* x, double* part, int N, int C, long S, 
 
 extern "C" int dca_bn_finalize(const double* part, int nchunk, double count, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, float momentum, float eps, int training,
-                               float* stats, int* zexps, int C, hipStream_t stream) {
+                               float* stats, int* zexps, const unsigned* rpre_slots, int rpre_n,
+                               const unsigned* rpost_slots, int rpost_n, int C, hipStream_t stream) {
   DCA_REQUIRE(stats && C > 0 && (training ? (part != nullptr && nchunk > 0) : (running_mean && running_var)));
   DCA_REQUIRE(zexps == nullptr || training);      // the bound behind zexps holds for batch statistics only
+  DCA_REQUIRE((rpre_slots == nullptr || (rpre_n > 0 && rpre_n <= DCA_AMAX_CSLOTS)) &&
+              (rpost_slots == nullptr || (rpost_n > 0 && rpost_n <= DCA_AMAX_CSLOTS)));
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, stream, part, nchunk, count, gamma, beta,
-                     running_mean, running_var, momentum, eps, training, stats, zexps, C);
+                     running_mean, running_var, momentum, eps, training, stats, zexps, rpre_slots, rpre_n, rpost_slots,
+                     rpost_n, C);
   return dca_launch_status();
 }
 
 extern "C" int dca_bn_finalize_centered(const double* part, int nchunk, const float* gamma, const float* beta,
                                         float* running_mean, float* running_var, float momentum, float eps, float* stats,
-                                        int* zexps, int C, hipStream_t stream) {
+                                        int* zexps, const unsigned* rpre_slots, int rpre_n, const unsigned* rpost_slots,
+                                        int rpost_n, int C, hipStream_t stream) {
   DCA_REQUIRE(part && nchunk > 0 && stats && C > 0 && ((running_mean == nullptr) == (running_var == nullptr)));
+  DCA_REQUIRE((rpre_slots == nullptr || (rpre_n > 0 && rpre_n <= DCA_AMAX_CSLOTS)) &&
+              (rpost_slots == nullptr || (rpost_n > 0 && rpost_n <= DCA_AMAX_CSLOTS)));
   hipLaunchKernelGGL(bn_finalize_centered_kernel, dim3(C), dim3(64), 0, stream, part, nchunk, gamma, beta, running_mean,
-                     running_var, momentum, eps, stats, zexps, C);
+                     running_var, momentum, eps, stats, zexps, rpre_slots, rpre_n, rpost_slots, rpost_n, C);
   return dca_launch_status();
 }
 
@@ -918,13 +959,14 @@ extern "C" int dca_bn_apply(const float* y, const float* stats, const float* res
 }
 
 extern "C" int dca_bn_apply_pack(const float* y, const float* stats, const int* zexps, void* zp, int N, int C, long S,
-                                 float slope, unsigned* ymax, hipStream_t stream) {
+                                 float slope, unsigned* ymax, const float* res_pre, const float* res_post, float* zf,
+                                 unsigned* zmax, hipStream_t stream) {
   DCA_REQUIRE(y && zexps && zp && N > 0 && C > 0 && C % 8 == 0 && S > 0 && C / 8 <= 65535 && ((((uintptr_t)zp) & 15) == 0));
   DCA_REQUIRE(stats != nullptr || (ymax == nullptr && slope == 1.f));
   int nchunk; long len;
   chunking(S, C / 8, &nchunk, &len);
   hipLaunchKernelGGL(bn_apply_pack_kernel, dim3(nchunk, C / 8), dim3(256), 0, stream, y, stats, zexps, (char*)zp, N, C, S,
-                     len, slope, ymax);
+                     len, slope, ymax, res_pre, res_post, zf, zmax);
   return dca_launch_status();
 }
 

@@ -16,8 +16,8 @@ class _DeconvBn3d(nn.Sequential):
         super().__init__(nn.ConvTranspose3d(cin, cout, 3, padding=1, output_padding=1, stride=2, bias=False),
                          nn.BatchNorm3d(cout))
 
-    def forward(self, x, slope=1.0, res_pre=None, res_post=None):
-        return ops.convbn3d(x, self[0], self[1], slope, res_pre, res_post)
+    def forward(self, x, slope=1.0, res_pre=None, res_post=None, pack_out=False):
+        return ops.convbn3d(x, self[0], self[1], slope, res_pre, res_post, pack_out=pack_out)
 
 
 class Multi_Aggregation(nn.Module):
@@ -38,7 +38,9 @@ class Multi_Aggregation(nn.Module):
                                      pack_a=True)
         c2 = self.conv2(c1)
         # relu(conv3(c2) + redir(x)) [+ res_post, fused: the caller's `cost0 + augmented_cost`]
-        return self.conv3(c2, slope=0.0, res_pre=skip, res_post=res_post)
+        # (the block's output is read by the next classifier head's 3x3x3 convolution -- through a packed twin -- and by the
+        # next block's pooling / `fuse` as fp32)
+        return self.conv3(c2, slope=0.0, res_pre=skip, res_post=res_post, pack_out="both")
 
 
 class _Downsample(nn.Sequential):

@@ -74,7 +74,9 @@ class _Dres0(nn.Sequential):
 
     def forward(self, x):
         # the first layer's only consumer is the second convolution: packed px2 operand in training (ops.convbn3d)
-        return self[2](self[0](x, slope=0.0, pack_out=True), slope=0.0)
+        # the result (cost0 before the residual block) is read by dres1's first convolution AND as its residual: fp32 plus
+        # a packed twin for the convolution
+        return self[2](self[0](x, slope=0.0, pack_out=True), slope=0.0, pack_out="both")
 
 
 class _Dres1(nn.Sequential):
@@ -88,7 +90,8 @@ class _Dres1(nn.Sequential):
         # the residual reads x through the first convolution's alias output: its gradient is added inside that convolution's
         # backward-data launch (ops._Conv3d.forward, `alias`)
         h, xa = self[0](x, slope=0.0, alias=True, pack_out=True)
-        return self[2](h, slope=1.0, res_post=xa)
+        # cost0: read by classif0's / classif3's convolution (packed twin) and by the pooling, `fuse` and residual adds (fp32)
+        return self[2](h, slope=1.0, res_post=xa, pack_out="both")
 
 
 class GwcNet(nn.Module):

@@ -341,8 +341,24 @@ def _tag_px2(t, exps):
     return t
 
 
+def _copy_tags(src, dst):
+    """the operand tags of src on dst, a view of the same values (the alias output of _Conv3d)"""
+    for k in ("_dca_cmax", "_dca_exps", "_dca_twin"):
+        v = getattr(src, k, None)
+        if v is not None:
+            setattr(dst, k, v[:-1] + (_ver(dst),))
+
+
 def _is_packed(t):
     return getattr(t, "_dca_px2", None) is not None
+
+
+def _twin_of(t):
+    """the packed px2 twin of the fp32 tensor t (written together with t by the BatchNorm apply pass), or None"""
+    tw = getattr(t, "_dca_twin", None)
+    if tw is not None and tw[0] is not None and tw[1] == _ver(t) and tw[0].device == t.device:
+        return tw[0]
+    return None
 
 
 def _slots_of(t):
@@ -392,7 +408,8 @@ def pack_x2(x):
     S = x[0, 0].numel()
     ex = _exps_of(x)
     xp = torch.empty_like(x)
-    _chk(_L().dca_bn_apply_pack(_ptr(x), None, _ptr(ex), _ptr(xp), N, C, S, 1.0, None, _stream()), "dca_bn_apply_pack")
+    _chk(_L().dca_bn_apply_pack(_ptr(x), None, _ptr(ex), _ptr(xp), N, C, S, 1.0, None, None, None, None, None, _stream()),
+         "dca_bn_apply_pack")
     return _tag_px2(xp, ex)
 
 
@@ -710,22 +727,40 @@ class _Conv3d(torch.autograd.Function):
         ctx.x_px2 = getattr(x, "_dca_px2", None)    # save_for_backward keeps the tensor, not its Python attributes
         ctx.packed_dy = bool(packed_dy)              # the gradient of y arrives as a packed px2 operand (_BnAct, pack_dy)
         ctx.x_exps = None
+        # a packed twin of x (written beside it by its BatchNorm): this convolution and its weight gradient read the twin
+        xt = None
+        if (PACK and CONV_X2 and x2 is None and not transposed and stride == 1 and weight.shape[2] == 3 and weight.shape[0] > 1
+                and _x3_eligible(x, None, 3, 1, False, weight.shape[1], weight.shape[0])):
+            xt = _twin_of(x)
+        ctx.x_twin = xt
+        xin = x if xt is None else xt
         with torch.cuda.device_of(x):
             if not want_stats:
-                y = _conv_forward_impl(x, x2, weight, stride, transposed)
-                ctx.x_exps = _exps_cached(x)         # forward and weight gradient scale x by the same exponents
-                return (y, x.view_as(x)) if alias else y
-            y, part = _conv_forward_impl(x, x2, weight, stride, transposed, want_stats=True)
-            ctx.x_exps = _exps_cached(x)
+                y = _conv_forward_impl(xin, x2, weight, stride, transposed)
+                ctx.x_exps = _exps_cached(xin)         # forward and weight gradient scale x by the same exponents
+                if alias:
+                    xa = x.view_as(x)
+                    _copy_tags(x, xa)
+                    return y, xa
+                return y
+            y, part = _conv_forward_impl(xin, x2, weight, stride, transposed, want_stats=True)
+            ctx.x_exps = _exps_cached(xin)
         if part is None:
             part = torch.empty((0,), device=x.device, dtype=torch.float64)
         ctx.mark_non_differentiable(part)
-        return (y, part, x.view_as(x)) if alias else (y, part)
+        if alias:
+            xa = x.view_as(x)
+            _copy_tags(x, xa)
+            return y, part, xa
+        return y, part
 
     @staticmethod
     def backward(ctx, dy, *rest):
         x, x2, weight = ctx.saved_tensors
-        if ctx.x_px2 is not None:
+        xw = x                                      # the operand of the weight gradient
+        if ctx.x_twin is not None:
+            xw = ctx.x_twin                         # (tagged px2 when it was written)
+        elif ctx.x_px2 is not None:
             x._dca_px2 = ctx.x_px2
         elif ctx.x_exps is not None and _exps_cached(x) is None:
             x._dca_exps = (ctx.x_exps, _ver(x))
@@ -761,7 +796,7 @@ class _Conv3d(torch.autograd.Function):
                             raise RuntimeError("stride-2 conv backward needs even input dims")
                 if need_w:
                     gw = torch.empty_like(weight)
-                    _wgrad(x, dy, gw, 0, Cin, Cout, 3, stride, Cin * K, K)
+                    _wgrad(xw, dy, gw, 0, Cin, Cout, 3, stride, Cin * K, K)
             else:
                 Cout, Cin = weight.shape[0], weight.shape[1]
                 w2 = weight.reshape(Cout, Cin)
@@ -863,10 +898,14 @@ def conv3d_fused_inference(x, weight, stride, transposed, scale, shift, slope, r
 # ------------------------------------------------------------------------------------------------
 # BatchNorm3d + activation + residual
 # ------------------------------------------------------------------------------------------------
-def bn_stats_vector(y, gamma, beta, running_mean, running_var, training, momentum, eps, part=None, zexps=None):
+def bn_stats_vector(y, gamma, beta, running_mean, running_var, training, momentum, eps, part=None, zexps=None,
+                    rpre=None, rpost=None):
     """[mean | invstd | scale | shift] (4*C floats); updates the running stats in place when training.
     part: partial statistics the producing convolution already emitted (dca_*_forward_stats), or None.
-    zexps (training only): C ints that receive the scale exponents of z = act(BN(y)) for the packed px2 output."""
+    zexps (training only): C ints that receive the scale exponents of z = act(BN(y) + res_pre) + res_post for the packed px2
+    output; rpre / rpost = (slots, nslots) of the residual tensors (their per-channel maxima enter the bound)."""
+    rps, rpn = rpre if rpre is not None else (None, 0)
+    rqs, rqn = rpost if rpost is not None else (None, 0)
     N, C = y.shape[0], y.shape[1]
     S = y[0, 0].numel()
     stats = torch.empty((4 * C,), device=y.device, dtype=torch.float32)
@@ -875,19 +914,20 @@ def bn_stats_vector(y, gamma, beta, running_mean, running_var, training, momentu
         if part is not None:     # one self-centred partial {K, n, s, q} per (channel, workgroup) of the producing conv
             _chk(lib.dca_bn_finalize_centered(_ptr(part), part.numel() // (4 * C), _ptr(gamma), _ptr(beta),
                                               _ptr(running_mean), _ptr(running_var), float(momentum), float(eps),
-                                              _ptr(stats), _ptr(zexps), C, _stream()), "dca_bn_finalize_centered")
+                                              _ptr(stats), _ptr(zexps), _ptr(rps), rpn, _ptr(rqs), rqn, C, _stream()),
+                 "dca_bn_finalize_centered")
             return stats
         nchunk = lib.dca_bn_num_chunks(C, S)
         part = torch.empty((C * nchunk * 2 + C,), device=y.device, dtype=torch.float64)   # partial sums + C shifts
         _chk(lib.dca_bn_stats(_ptr(y), _ptr(part), N, C, S, _stream()), "dca_bn_stats")
         _chk(lib.dca_bn_finalize(_ptr(part), nchunk, float(N * S), _ptr(gamma), _ptr(beta), _ptr(running_mean),
-                                 _ptr(running_var), float(momentum), float(eps), 1, _ptr(stats), _ptr(zexps), C, _stream()),
-             "dca_bn_finalize")
+                                 _ptr(running_var), float(momentum), float(eps), 1, _ptr(stats), _ptr(zexps), _ptr(rps), rpn,
+                                 _ptr(rqs), rqn, C, _stream()), "dca_bn_finalize")
     else:
         assert zexps is None
         _chk(lib.dca_bn_finalize(None, 0, float(N * S), _ptr(gamma), _ptr(beta), _ptr(running_mean),
-                                 _ptr(running_var), float(momentum), float(eps), 0, _ptr(stats), None, C, _stream()),
-             "dca_bn_finalize")
+                                 _ptr(running_var), float(momentum), float(eps), 0, _ptr(stats), None, None, 0, None, 0, C,
+                                 _stream()), "dca_bn_finalize")
     return stats
 
 
@@ -898,7 +938,7 @@ def bn_eval_affine(bn):
     def build():
         stats = torch.empty((4 * C,), device=bn.running_mean.device, dtype=torch.float32)
         _chk(_L().dca_bn_finalize(None, 0, 1.0, _ptr(bn.weight), _ptr(bn.bias), _ptr(bn.running_mean),
-                                  _ptr(bn.running_var), 0.1, float(bn.eps), 0, _ptr(stats), None, C, _stream()),
+                                  _ptr(bn.running_var), 0.1, float(bn.eps), 0, _ptr(stats), None, None, 0, None, 0, C, _stream()),
              "dca_bn_finalize")
         return stats
     src = tuple(t for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var) if t is not None)
@@ -907,7 +947,9 @@ def bn_eval_affine(bn):
 
 class _BnAct(torch.autograd.Function):
     """z = act(BN(y) + res_pre) + res_post with nn.BatchNorm3d semantics.
-    pack_z:  z is written in the packed px2 operand format (for ONE consumer: an f16x2 convolution) instead of fp32.
+    pack_z:  1: z is written in the packed px2 operand format (for ONE consumer: an f16x2 convolution) instead of fp32;
+             2: both -- the fp32 z for all readers and a packed twin (it rides on z: _dca_twin) for the f16x2 convolution
+             among them and its weight gradient.
     pack_dy: backward writes the gradient of y in the packed px2 format (y's producer is an f16x2 convolution: its
              backward-data and weight-gradient kernels are the only readers)."""
 
@@ -920,17 +962,24 @@ class _BnAct(torch.autograd.Function):
         N, C = y.shape[0], y.shape[1]
         S = y[0, 0].numel()
         lib = _L()
-        pack_z = bool(pack_z and training and res_pre is None and res_post is None and C % 8 == 0)
+        pack_z = int(pack_z) if (training and C % 8 == 0) else 0
         pack_dy = bool(pack_dy and res_pre is None and C % 8 == 0)
         with torch.cuda.device_of(y):
             zexps = torch.empty((C,), device=y.device, dtype=torch.int32) if pack_z else None
-            stats = bn_stats_vector(y, gamma, beta, running_mean, running_var, training, momentum, eps, part, zexps)
+            rpre = _slots_of(res_pre) if (pack_z and res_pre is not None) else None
+            rpost = _slots_of(res_post) if (pack_z and res_post is not None) else None
+            stats = bn_stats_vector(y, gamma, beta, running_mean, running_var, training, momentum, eps, part, zexps, rpre, rpost)
             ymax = torch.empty((C * CSLOTS,), device=y.device, dtype=torch.int32) if pack_dy else None
             z = torch.empty_like(y)
+            _tls.last_twin = None
             if pack_z:
-                _chk(lib.dca_bn_apply_pack(_ptr(y), _ptr(stats), _ptr(zexps), _ptr(z), N, C, S, float(slope), _ptr(ymax),
-                                           _stream()), "dca_bn_apply_pack")
+                zp = z if pack_z == 1 else torch.empty_like(y)
+                _chk(lib.dca_bn_apply_pack(_ptr(y), _ptr(stats), _ptr(zexps), _ptr(zp), N, C, S, float(slope), _ptr(ymax),
+                                           _ptr(res_pre), _ptr(res_post), _ptr(z) if pack_z == 2 else None,
+                                           _ptr(zmax) if pack_z == 2 else None, _stream()), "dca_bn_apply_pack")
                 ymax_slots = lib.dca_bn_pack_chunks(C, S)
+                if pack_z == 2:
+                    _tls.last_twin = _tag_px2(zp, zexps)
             else:
                 _chk(lib.dca_bn_apply(_ptr(y), _ptr(stats), _ptr(res_pre), _ptr(res_post), _ptr(z), N, C, S, float(slope),
                                       _ptr(zmax), _ptr(ymax), _stream()), "dca_bn_apply")
@@ -1112,21 +1161,26 @@ class batched_bn_counters:
 def bn_act(y, bn, slope=1.0, res_pre=None, res_post=None, stats_part=None, pack_out=False, pack_dy=False):
     """Applies the nn.BatchNorm3d module `bn` (parameters/buffers only; its forward is never called).
     stats_part: batch-statistics partial sums of y from the producing convolution (`_Conv3d` with want_stats), if it made them.
-    pack_out: the result has ONE consumer, an f16x2 3x3x3 stride-1 convolution: write it in the packed px2 operand format
-    (training BatchNorm without residuals only; plain fp32 otherwise).  pack_dy: see _BnAct."""
+    pack_out: True -- the result has ONE consumer, an f16x2 3x3x3 stride-1 convolution: write it in the packed px2 operand
+    format instead of fp32; "both" -- several consumers, ONE of them such a convolution: fp32 result plus a packed twin that
+    this convolution and its weight gradient pick up (training BatchNorm only; plain fp32 otherwise).  pack_dy: see _BnAct."""
     momentum = 0.1 if bn.momentum is None else bn.momentum
     training = bn.training or bn.running_mean is None
     if _lp_dtype() is not None:
         raise RuntimeError("ops.reduced_precision is inference only: call the model in eval mode under torch.no_grad()")
     C = y.shape[1]
-    pack_z = bool(pack_out and PACK and CONV_X2 and training and res_pre is None and res_post is None and C % 8 == 0
-                  and torch.is_grad_enabled())
+    pack_z = 0
+    if pack_out and PACK and CONV_X2 and training and C % 8 == 0 and torch.is_grad_enabled():
+        pack_z = 2 if pack_out == "both" else 1
     pack_dy = bool(pack_dy and PACK and CONV_X2 and res_pre is None and C % 8 == 0)
-    zm = _cslots(C, y.device) if (CONV_X2 and not pack_z) else None     # per-channel max |z|: the next convolution's operand scales
+    zm = _cslots(C, y.device) if (CONV_X2 and pack_z != 1) else None    # per-channel max |z|: the next convolution's operand scales
     z = _BnAct.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, float(slope),
                      res_pre, res_post, stats_part if training else None, zm, pack_z, pack_dy)
-    if pack_z:
+    if pack_z == 1:
         _tag_px2(z, _tls.last_zexps)
+    elif pack_z == 2:
+        z._dca_twin = (_tls.last_twin, _ver(z))
+        _tag_cmax(z, zm, _L().dca_bn_pack_chunks(C, y[0, 0].numel()))
     elif zm is not None:
         _tag_cmax(z, zm, _L().dca_bn_num_chunks(C, y[0, 0].numel()))
     if bn.training and bn.num_batches_tracked is not None:

@@ -23,7 +23,7 @@ extern "C" {
 
 /* Bumped whenever an argument list below changes; the ctypes loader (_lib.py) refuses a library built from another
  * version of this header. */
-#define DCA_ABI_VERSION 13
+#define DCA_ABI_VERSION 14
 int dca_abi_version(void);
 
 /* storage types of the reduced-precision inference path (0 = fp32) */
@@ -176,7 +176,8 @@ int dca_deconv3d_x3_forward_stats(const float* x, const void* wx, float* y, doub
 /* [mean | invstd | scale | shift] (4*C floats) from those partials, with the running-statistics update of training-mode
  * nn.BatchNorm3d (momentum, unbiased variance); running_mean / running_var may both be null. */
 int dca_bn_finalize_centered(const double* part, int nchunk, const float* gamma, const float* beta, float* running_mean,
-                             float* running_var, float momentum, float eps, float* stats, int* zexps, int C,
+                             float* running_var, float momentum, float eps, float* stats, int* zexps,
+                             const unsigned* rpre_slots, int rpre_n, const unsigned* rpost_slots, int rpost_n, int C,
                              hipStream_t stream);
 
 /* Weight gradient of the 3x3x3 / stride-1 / pad-1 convolution on the bf16 matrix pipe with the same exact three-way
@@ -261,10 +262,12 @@ int dca_conv3d_c1_bwd_data(const float* dy, const float* w, float* dx, int N, in
  * zmax / dmax (dca_bn_apply: of z, dca_bn_backward: of dy; may be null): per-channel slots (see "f16x2" above; nslots =
  *                  dca_bn_num_chunks(C, S)) that receive max |.| of the tensor written; ymax (dca_bn_apply[_pack]; may be
  *                  null): slots that receive max |y - mean| per channel (it bounds |xhat| for the backward pass' scale).
- * zexps (dca_bn_finalize[_centered]; may be null, training only): per-channel scale exponents for z = act(BN(y)) from the
- *                  bound |z| <= |gamma| sqrt(count) + |beta| -- known before z is written, so that
- * dca_bn_apply_pack writes z directly in the packed px2 format (no residuals; stats = null: plain packing of y with zexps);
- *                  nslots of its ymax = dca_bn_pack_chunks(C, S).
+ * zexps (dca_bn_finalize[_centered]; may be null, training only): per-channel scale exponents for z = act(BN(y) + res_pre) +
+ *                  res_post from the bound |z| <= |gamma| sqrt(count) + |beta| + max |res_pre| + max |res_post| (the residual
+ *                  tensors' per-channel slots rpre_slots / rpost_slots, may be null) -- known before z is written, so that
+ * dca_bn_apply_pack writes z directly in the packed px2 format (stats = null: plain packing of y with zexps) and, with
+ *                  zf != null, a second fp32 copy for the other readers of z (zmax: its per-channel slots); nslots of ymax / zmax =
+ *                  dca_bn_pack_chunks(C, S).
  * dca_bn_backward_pack: dca_bn_backward (no res_pre / g_out) writing dy in the packed px2 format; dyexps (C ints, out) =
  *                  the exponents it was scaled by (bound from max |g|, this launch's reduce pass, and max |xhat| = invstd *
  *                  ymax); gmax = scratch of C * DCA_AMAX_CSLOTS words. */
@@ -273,11 +276,13 @@ int dca_bn_pack_chunks(int C, long S);
 int dca_bn_stats(const float* x, double* part, int N, int C, long S, hipStream_t stream);
 int dca_bn_finalize(const double* part, int nchunk, double count, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float momentum, float eps, int training, float* stats,
-                    int* zexps, int C, hipStream_t stream);
+                    int* zexps, const unsigned* rpre_slots, int rpre_n, const unsigned* rpost_slots, int rpost_n, int C,
+                    hipStream_t stream);
 int dca_bn_apply(const float* y, const float* stats, const float* res_pre, const float* res_post, float* z, int N,
                  int C, long S, float slope, unsigned* zmax, unsigned* ymax, hipStream_t stream);
 int dca_bn_apply_pack(const float* y, const float* stats, const int* zexps, void* zp, int N, int C, long S, float slope,
-                      unsigned* ymax, hipStream_t stream);
+                      unsigned* ymax, const float* res_pre, const float* res_post, float* zf, unsigned* zmax,
+                      hipStream_t stream);
 int dca_bn_backward(const float* dz, const float* y, const float* res_pre, const float* stats, double* part,
                     float* dgb, float* dy, float* g_out, int N, int C, long S, float slope, int training,
                     unsigned* dmax, hipStream_t stream);

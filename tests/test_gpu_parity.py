@@ -757,15 +757,20 @@ def test_bn_pack_kernels_match_fp32_kernels(slope, monkeypatch):
             assert torch.equal(a, b), name
 
 
-def test_packed_training_chain_matches_fp32_chain(monkeypatch):
-    """conv -> BN -> ReLU -> conv -> BN (+ residual) trained one step with packed px2 operands between the layers (z1 and
-    both gradients dy1, dy2 never exist as fp32 tensors) against the same chain with fp32 operands everywhere and against
-    PyTorch in fp64: same accuracy class"""
+@pytest.mark.parametrize("both", [False, True], ids=["packed-only", "fp32+twin"])
+def test_packed_training_chain_matches_fp32_chain(both, monkeypatch):
+    """conv -> BN -> ReLU -> conv -> BN (+ residual) trained one step with packed px2 operands between the layers against the
+    same chain with fp32 operands everywhere and against PyTorch in fp64: same accuracy class.
+      packed-only: z1 and both gradients dy1, dy2 never exist as fp32 tensors (z1 has one reader);
+      fp32+twin:   z1 is ALSO the residual of the second layer, so its BatchNorm writes fp32 AND a packed twin (pack_out =
+                   "both") that the convolution and its weight gradient read; the second layer's output, with that
+                   residual, is written both ways too (its bound includes the residual's per-channel maxima)."""
     _, ops = _mods()
     import torch.nn as nn
     _family(monkeypatch, ops, "f16x2")
     c1 = nn.Conv3d(40, 32, 3, 1, 1, bias=False).to(DEV); b1 = nn.BatchNorm3d(32).to(DEV)
     c2 = nn.Conv3d(32, 32, 3, 1, 1, bias=False).to(DEV); b2 = nn.BatchNorm3d(32).to(DEV)
+    c3 = nn.Conv3d(32, 32, 3, 1, 1, bias=False).to(DEV)
     x = seeded_tensor("pch.x", (2, 40, 6, 10, 24)).to(DEV)
     r = seeded_tensor("pch.r", (2, 32, 6, 10, 24)).to(DEV)
     gz = seeded_tensor("pch.g", (2, 32, 6, 10, 24)).to(DEV) * 1e-3
@@ -776,7 +781,17 @@ def test_packed_training_chain_matches_fp32_chain(monkeypatch):
             b.reset_running_stats()
         before = dict(ops.AMAX_STATS)
         xx = x.clone().requires_grad_()
-        z = ops.convbn3d(ops.convbn3d(xx, c1, b1, 0.0, pack_out=True), c2, b2, 1.0, res_post=r)
+        if both:
+            z1 = ops.convbn3d(xx, c1, b1, 0.0, pack_out="both")
+            z2 = ops.convbn3d(z1, c2, b2, 1.0, res_post=z1, pack_out="both")
+            if pack:
+                assert ops._twin_of(z1) is not None and ops._twin_of(z2) is not None and not ops._is_packed(z2)
+                tw = ops._twin_of(z2)
+                err = _chan_err(_unpack_px2(tw, tw._dca_px2[0]), z2)
+                assert err.max() <= 2.0 ** -21, err.max().item()
+            z = ops.conv3d(z2, c3.weight, 1, False) + z2            # a 3x3x3 reader (twin) and an fp32 reader of z2
+        else:
+            z = ops.convbn3d(ops.convbn3d(xx, c1, b1, 0.0, pack_out=True), c2, b2, 1.0, res_post=r)
         g = torch.autograd.grad((z * gz).sum(), [xx, c1.weight, c2.weight, b1.weight, b1.bias])
         res[pack] = [z.detach()] + [t.detach() for t in g]
         if pack:
@@ -786,7 +801,12 @@ def test_packed_training_chain_matches_fp32_chain(monkeypatch):
                       nn.BatchNorm3d(32)).double()
     m[0].weight.data.copy_(c1.weight.detach().cpu()); m[3].weight.data.copy_(c2.weight.detach().cpu())
     xr = x.cpu().double().requires_grad_()
-    zr = m(xr) + r.cpu().double()
+    if both:
+        z1r = m[2](m[1](m[0](xr)))
+        z2r = m[4](m[3](z1r)) + z1r
+        zr = F.conv3d(z2r, c3.weight.detach().cpu().double(), None, 1, 1) + z2r
+    else:
+        zr = m(xr) + r.cpu().double()
     gr = torch.autograd.grad((zr * gz.cpu().double()).sum(), [xr, m[0].weight, m[3].weight, m[1].weight, m[1].bias])
     for i, (a, b, ref) in enumerate(zip(res[True], res[False], [zr] + list(gr))):
         ea, eb = rel_l2(a, ref), rel_l2(b, ref)
