@@ -372,36 +372,6 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
   store_A(0);
   __syncthreads();
 
-  // Deferred epilogue (EPI 0; not the fp32-operand statistics variant, which has no registers to spare): a tile's scaled
-  // results wait in pacc[] and are stored -- and their BatchNorm statistics taken -- between the MFMAs of the NEXT tile's first
-  // chunk, three values per tap pair, instead of in a block of 32 store instructions per wave during which the matrix pipe
-  // of the SIMD idles (1.8 k cycles for the older wave of a SIMD, 3.0-3.8 k for the younger one, of a 30-32 k cycle tile:
-  // s_memtime stamps, tools/x2_stamps.py).
-  constexpr bool DEFER = (EPI == 0) && (PIN || !STATS);
-  f32x16 pacc[2];
-  int p_n = 0, p_d0 = 0, p_h0 = 0, p_w0 = 0;
-  bool have_prev = false;
-  const long osample_ = (long)a.Cout * cstride;
-  // one deferred value: statistics + store of v = the scaled result of column tile t, accumulator register r
-  auto epi_store = [&](int t, int r, float v, __amdgpu_buffer_rsrc_t yr, int voff, int ok) __attribute__((always_inline)) {
-    const int cu = (r & 3) + 8 * (r >> 2);
-    if constexpr (STATS) {
-      if (stat_first && t == 0) {   // the wave's first tile: the shift of (half, r) = what lane 0 of the half produced
-        st_k[r] = fs_half_first(v, half);
-        if ((lane & 31) == 0) fs_slot(stat_w, half, r)[0] = st_k[r];     // fs_flush reads it there
-      }
-      const float dlt = ok ? v - st_k[r] : 0.f;
-      st_s[r] += dlt;
-      st_q[r] = fmaf(dlt, dlt, st_q[r]);
-    }
-    dca_bstore1(yr, v, voff + cu * cstride * 4, ok & (int)(cblk * 32 + cu + 4 * half < a.Cout));
-  };
-  auto epi_coords = [&](int t, int d0_, int h0_, int w0_, int& voff, int& ok) __attribute__((always_inline)) {
-    const int r0 = (wv * 2 + t) * 2 + (l31 >> 4), d = d0_ + (r0 >> 3), h = h0_ + (r0 & 7), w = w0_ + wlane;
-    ok = (int)(d < a.D) & (int)(h < a.H) & (int)(w < a.W);
-    voff = ((d * a.H + h) * a.W + w + (cblk * 32 + 4 * half) * cstride) * 4;
-  };
-
   int buf = 0;  // image pair (A, B) of the current chunk; chunks alternate buffers across tile boundaries
 #pragma unroll 1
   for (int tile = t_begin; tile < t_end; tile += t_step) {
@@ -436,16 +406,6 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
         if (stage) {
           load_B(s_n, s_d0, s_h0, s_w0, s_chunk);
           load_A(s_chunk);
-        }
-      }
-      const bool defer_now = DEFER && have_prev && chunk == 0;
-      __amdgpu_buffer_rsrc_t p_yr = dca_rsrc(a.y + (long)p_n * osample_, osample_ * 4);
-      int p_voff[2] = {0, 0}, p_ok[2] = {0, 0};
-      if (defer_now) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          epi_coords(t, p_d0, p_h0, p_w0, p_voff[t], p_ok[t]);
-          if constexpr (STATS) st_n += (float)p_ok[t];
         }
       }
       const char* ab = a_lds + buf * A_CHUNK + lane * 16;
@@ -499,17 +459,6 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
           }
         }
         __builtin_amdgcn_sched_barrier(0);     // nothing moves across pairs: the staging steps stay where they are written
-        if constexpr (DEFER) {
-          if (defer_now) {      // the previous tile's results 3p .. 3p+2 (of 32)
-#pragma unroll
-            for (int idx = 3 * p; idx < 3 * p + 3; ++idx)
-              if (idx < 32) epi_store(idx >> 4, idx & 15, pacc[idx >> 4][idx & 15], p_yr, p_voff[idx >> 4], p_ok[idx >> 4]);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      if constexpr (DEFER && STATS) {
-        if (defer_now) stat_first = false;
       }
       X2_MARK(2);
       if constexpr (!PIN && !VEC) {
@@ -553,14 +502,6 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
       const int4 f4 = *(const int4*)(fo_lds + 8 * q + 4 * half);
       nfo[4 * q] = -f4.x; nfo[4 * q + 1] = -f4.y; nfo[4 * q + 2] = -f4.z; nfo[4 * q + 3] = -f4.w;
     }
-    if constexpr (DEFER) {     // park the scaled results; they are written out under the next tile's first chunk
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) pacc[t][r] = ldexpf(acc[t][r], nfo[r]);
-      p_n = n; p_d0 = d0; p_h0 = h0; p_w0 = w0;
-      have_prev = true;
-    } else {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int r0 = (wv * 2 + t) * 2 + (l31 >> 4), d = d0 + (r0 >> 3), h = h0 + (r0 & 7), w = w0 + wlane;
@@ -613,26 +554,12 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
       }
     }
     if constexpr (STATS) stat_first = false;
-    }
     X2_MARK(7);
     __syncthreads();     // (the last chunk's barrier: the next tile's first images are complete, this tile's are free)
 #if X2_STAMP
     ++stamp_k;
 #endif
     n = nn; d0 = nd0; h0 = nh0; w0 = nw0;
-  }
-  if constexpr (DEFER) {      // the last tile's results
-    if (have_prev) {
-      const __amdgpu_buffer_rsrc_t p_yr = dca_rsrc(a.y + (long)p_n * osample_, osample_ * 4);
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        int voff, ok;
-        epi_coords(t, p_d0, p_h0, p_w0, voff, ok);
-        if constexpr (STATS) st_n += (float)ok;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) epi_store(t, r, pacc[t][r], p_yr, voff, ok);
-      }
-    }
   }
   if constexpr (STATS) {
 #pragma unroll
