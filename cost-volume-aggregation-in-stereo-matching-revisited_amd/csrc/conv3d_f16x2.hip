@@ -79,8 +79,6 @@ constexpr int A_CHUNK = NPAIR * NT * 1024;         // weight fragments of a chun
 constexpr int LDS_BYTES = 2 * B_BYTES + 2 * A_CHUNK;   // both images double buffered: 126464 of the CU's 163840
 constexpr int MAX_CIN = 256;                       // the per-channel exponent table below
 constexpr int TAB_BYTES = (MAX_CIN + 32 + 8 * 32) * 4;   // xexps[MAX_CIN] | f_o[32] | per-wave channel maxima [8][32]
-constexpr int EPI_WAVE = 16 * 32 * 4;              // epilogue transposition area of a wave: 16 channels x 32 voxels x fp32
-constexpr int EPI_BYTES = 8 * EPI_WAVE;            // 16384
 constexpr int NP_ITEMS = NT * NVOX;                // packed-input staging: 2160 16-byte words per chunk = the LDS image itself
 constexpr int KP = (NP_ITEMS + 511) / 512;         // 5 per thread
 constexpr int KB = (NVOX + 511) / 512;             // 3 single-voxel staging items of 8 channels per thread (unaligned path)
@@ -106,7 +104,6 @@ struct X2Args {
   const int* xexps;          // fp32 x: the scale exponent of every input channel (Cin ints); unused for packed x
   const int* ofo;            // behind the packed weight image: f_o of every output channel (dca_conv3d_x2_prep_weight)
   unsigned* y_cmax;          // optional (EPI 1): per-channel slots [c][blockIdx.x] that receive max |y| (dca_common.h)
-  int wide;                  // W % 4 == 0 and y 16-byte aligned: 16-byte result stores through the LDS transposition area
 #if X2_STAMP
   unsigned long long* stamps;   // debug build: s_memtime stamps of workgroup 0, waves 0 and 7 (2 x 96 x 8 words)
 #endif
@@ -138,8 +135,7 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
   int* xe_lds = (int*)(smem + LDS_BYTES);           // scale exponents of the input channels (fp32 x)
   int* fo_lds = xe_lds + MAX_CIN;                   // f_o of this block's 32 output channels
   float* ycm_lds = (float*)(fo_lds + 32);           // [wave][channel] maxima (y_cmax)
-  float* epi_lds = (float*)(smem + LDS_BYTES + TAB_BYTES) + (threadIdx.x >> 6) * (EPI_WAVE / 4);   // this wave's epilogue area
-  float* stat_lds = (float*)(smem + LDS_BYTES + TAB_BYTES + EPI_BYTES);     // STATS only (the launch adds STAT_LDS bytes)
+  float* stat_lds = (float*)(smem + LDS_BYTES + TAB_BYTES);     // STATS only (the launch adds STAT_LDS bytes)
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, half = lane >> 5;
   const int cblk = blockIdx.y;
@@ -550,28 +546,11 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
         }
         const int okc = ok & (int)(cblk * 32 + cu + 4 * half < a.Cout);
         if constexpr (EPI == 1) ycm[r] = fmaxf(ycm[r], okc ? fabsf(v) : 0.f);
-        if (!a.wide) {
-          dca_bstore1(yr, v, voff + cu * cstride * 4, okc);
-        } else {
-          // 16-byte stores: the lane holds ONE voxel of 16 channels, a store wants 4 consecutive voxels of one channel -- 8
-          // registers (16 channels x 32 voxels) at a time go through a wave-private LDS area [channel][row][w] and come
-          // back as 128 words of 16 bytes, 2 per lane: 8 store instructions per wave and tile instead of 32 (the block of
-          // 32 four-byte stores took the older wave of a SIMD 1.8 k, the younger one 3.0 k cycles of a 30 k cycle tile)
-          const int chl = (r & 3) + 4 * half + 8 * ((r >> 2) & 1);          // channel within the group of 16
-          epi_lds[(chl * 2 + (l31 >> 4)) * 16 + wlane] = v;
-          if ((r & 7) == 7) {
-            const int g8 = r >> 3, rowt = (wv * 2 + t) * 2;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-              const int it = lane + 64 * k, wq = it & 3, j = (it >> 2) & 1, cl = it >> 3;
-              const float4 q4 = *(const float4*)(epi_lds + it * 4);
-              const int c = cblk * 32 + 16 * g8 + cl, rr = rowt + j, dd = d0 + (rr >> 3), hh = h0 + (rr & 7), ww = w0 + 4 * wq;
-              const int okq = (int)(c < a.Cout) & (int)(dd < a.D) & (int)(hh < a.H) & (int)(ww < a.W);
-              const u32x4 u = {__float_as_uint(q4.x), __float_as_uint(q4.y), __float_as_uint(q4.z), __float_as_uint(q4.w)};
-              __builtin_amdgcn_raw_buffer_store_b128(u, yr, dca_pred_off((c * cstride + (dd * a.H + hh) * a.W + ww) * 4, okq), 0, 0);
-            }
-          }
-        }
+#if X2_NT
+        dca_bstore1_nt(yr, v, voff + cu * cstride * 4, okc);
+#else
+        dca_bstore1(yr, v, voff + cu * cstride * 4, okc);
+#endif
       }
     }
     if constexpr (STATS) stat_first = false;
@@ -774,7 +753,6 @@ int x2_launch(const void* x, int packed, const int* xexps, const void* wx, float
   a.stat_part = stat_part;
   a.xexps = xexps;
   a.y_cmax = y_cmax;
-  a.wide = (W % 4 == 0) && ((((uintptr_t)y) & 15) == 0);
 #if X2_STAMP
   a.stamps = g_stamps;
 #endif
@@ -787,7 +765,7 @@ int x2_launch(const void* x, int packed, const int* xexps, const void* wx, float
   const bool full = scale != nullptr || res_pre != nullptr || slope != 1.f || y_cmax != nullptr;
   const int epi = full ? 1 : (res_post != nullptr ? 2 : 0);
   DCA_REQUIRE(!(stats && epi));    // the statistics are those of the raw convolution output
-  const int lds = LDS_BYTES + TAB_BYTES + EPI_BYTES + (stats ? STAT_LDS : 0);
+  const int lds = LDS_BYTES + TAB_BYTES + (stats ? STAT_LDS : 0);
   const int gx = x2_grid(tiles, cblks);
   if (packed) {
     DCA_REQUIRE(epi != 1);         // the packed operand exists in training only (BatchNorm kernels write it)
