@@ -467,10 +467,13 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     frozen.close()
+    rank_ms = [dt / args.steps * 1e3]
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        mine = torch.tensor([dt], device=device, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms = [float(v.item()) / args.steps * 1e3 for v in every]
+        dt = max(rank_ms) * args.steps / 1e3           # the job's time is its slowest rank's
 
     if rank == 0:
         volumes = args.steps * args.batch * world
@@ -506,6 +509,8 @@ def main():
                                    f"{H_IMG}x{W_IMG} D={MAXDISP}, " + ("train step: fwd(all heads)+focal/model loss+bwd+allreduce+Adam"
                                                         if args.mode == "fwdbwd" else "eval forward"),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "world_size": world, "collective_backend": (dist.get_backend() if world > 1 else None),
+                       "ms_per_step_by_rank": [round(v, 3) for v in rank_ms],
                        "mode": args.mode, "hipgraph": bool(args.graph) if args.mode == "fwd" else train_graphed,
                        **({"hipgraph_error": graph_error} if graph_error else {}),
                        "weight_prepack": "once (ops.frozen_weights)" if args.mode == "fwd" else
