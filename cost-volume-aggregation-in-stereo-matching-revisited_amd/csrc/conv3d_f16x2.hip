@@ -100,6 +100,7 @@ struct X2Args {
   int N, Cin, Cout, NCH;
   int D, H, W;
   int nTD, nTH, nTW;
+  int order;                 // tile traversal: 0 = w fastest (w, h, d, n), 1 = d fastest (d, w, h, n)
   double* stat_part;         // STATS: one partial {K, n, s, q} per (channel, workgroup): bn_fused_stats.h
   const int* xexps;          // fp32 x: the scale exponent of every input channel (Cin ints); unused for packed x
   const int* ofo;            // behind the packed weight image: f_o of every output channel (dca_conv3d_x2_prep_weight)
@@ -357,10 +358,18 @@ __global__ __launch_bounds__(512) void conv3_f16x2_kernel(X2Args a) {
     }
   };
   auto decode = [&](int tile, int& n, int& d0, int& h0, int& w0) __attribute__((always_inline)) {
-    const int tw = tile % a.nTW; tile /= a.nTW;
-    const int th = tile % a.nTH; tile /= a.nTH;
-    const int td = tile % a.nTD;
-    n = tile / a.nTD;
+    int td, th, tw;
+    if (a.order == 0) {
+      tw = tile % a.nTW; tile /= a.nTW;
+      th = tile % a.nTH; tile /= a.nTH;
+      td = tile % a.nTD;
+      n = tile / a.nTD;
+    } else {
+      td = tile % a.nTD; tile /= a.nTD;
+      tw = tile % a.nTW; tile /= a.nTW;
+      th = tile % a.nTH;
+      n = tile / a.nTH;
+    }
     d0 = td * TD; h0 = th * TH; w0 = tw * TW;
   };
 
@@ -751,6 +760,10 @@ int x2_launch(const void* x, int packed, const int* xexps, const void* wx, float
   a.D = D; a.H = H; a.W = W;
   a.nTD = cdiv(D, TD); a.nTH = cdiv(H, TH); a.nTW = cdiv(W, TW);
   a.stat_part = stat_part;
+  {
+    static const int order = [] { const char* e = getenv("DCA_X2_ORDER"); return e ? atoi(e) : 0; }();
+    a.order = order;
+  }
   a.xexps = xexps;
   a.y_cmax = y_cmax;
 #if X2_STAMP

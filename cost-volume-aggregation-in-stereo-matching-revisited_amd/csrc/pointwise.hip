@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   const long s0 = ch * chunk_len, s1 = min(S, s0 + chunk_len);
   const float mean = stats[c], sc = stats[2 * C + c], sh = stats[3 * C + c];
   float am = 0.f, ym = 0.f;
-  for (int n = 0; n < N; ++n) {
+  for (int n = N - 1; n >= 0; --n) {   // descending: see bn_bwd_reduce_kernel
     const long base = ((long)n * C + c) * S;
     if (vec) {
       for (long i = s0 + 4 * tid; i < s1; i += 1024) {
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void bn_apply_pack_kernel(const float* __restr
     ym[j] = zm[j] = 0.f;
   }
   const long tb = px2_term_bytes(C, S);
-  for (int n = 0; n < N; ++n) {
+  for (int n = N - 1; n >= 0; --n) {   // descending: see bn_bwd_reduce_kernel
     const float* yb = y + ((long)n * C + cg * 8) * S;
     char* zb = zp + (long)n * 2 * tb + (long)cg * S * 16;
     const long cb = ((long)n * C + cg * 8) * S;
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   const long s0 = ch * chunk_len, s1 = min(S, s0 + chunk_len);
   const float mean = stats[c], invstd = stats[C + c], sc = stats[2 * C + c], sh = stats[3 * C + c];
   float a0 = 0.f, a1 = 0.f, gm = 0.f;
-  for (int n = 0; n < N; ++n) {
+  for (int n = N - 1; n >= 0; --n) {   // the producer of dz wrote the last sample last: its tail is still in the infinity cache
     const long base = ((long)n * C + c) * S;
     if (vec) {
       for (long i = s0 + 4 * tid; i < s1; i += 1024) {

@@ -297,6 +297,7 @@ CONV_X3 = _CONV_MODE != "fp32"
 CONV_X2 = _CONV_MODE == "x2"
 WGRAD_S2_X2 = os.environ.get("DCA_WGRAD_S2", "x2") != "fp32"   # stride-2 / transposed weight gradient on the f16x2 split (A/B)
 DECONV_X3 = os.environ.get("DCA_DECONV", "x3") != "fp32"
+CONV_S2_X2 = os.environ.get("DCA_CONV_S2", "x2") != "fp32"     # the stride-2 convolution itself on the f16x2 split (A/B)
 BN_FUSE = os.environ.get("DCA_BN_FUSE", "1") != "0"        # BatchNorm batch statistics from the conv epilogue (training)   # the transposed-convolution member of the family alone (A/B timing)
 _X3_MIN_WORKGROUPS = 1
 
@@ -430,6 +431,20 @@ def _dx3_eligible(x, x2, ksize, stride, transposed, A, B):
     return W % 4 == 0 and x.data_ptr() % 16 == 0 and max(A, 8) * D * H * W * 4 < 0x7ffffff0 and 256 * D * H * W * 4 < 0x7ffffff0
 
 
+def _s2x2_eligible(x, x2, ksize, stride, transposed, A, B, scale, res_pre, slope):
+    """3x3x3 stride-2 convs on the f16x2 kernel of conv3d_s2_f16x2.hip: plain output (+ res_post), fine width divisible by 4,
+    16-byte aligned input, enough tiles to fill the chip (small volumes stay on the fp32 MFMA kernel)"""
+    if not (CONV_X2 and CONV_X3 and CONV_S2_X2) or ksize != 3 or stride != 2 or transposed or x2 is not None:
+        return False
+    if scale is not None or res_pre is not None or slope != 1.0 or A > 256:
+        return False
+    N, _, D, H, W = x.shape
+    Do, Ho, Wo = (D + 1) // 2, (H + 1) // 2, (W + 1) // 2
+    tiles = N * ((Do + 1) // 2) * ((Ho + 3) // 4) * ((Wo + 31) // 32) * ((B + 63) // 64)
+    return (W % 4 == 0 and x.data_ptr() % 16 == 0 and tiles >= _X3_MIN_WORKGROUPS
+            and (A + 3) * D * H * W * 4 < 0x7ffffff0 and (B + 63) * Do * Ho * Wo * 4 < 0x7ffffff0)
+
+
 def _c1x3_eligible(x, x2, ksize, A, C1, y):
     """1x1x1 convs on the bf16x3 kernel of conv1_x3.hip (fp32-grade, LDS-free): channel layouts it is built for, voxel
     count divisible by 4, 16-byte aligned tensors"""
@@ -547,6 +562,22 @@ def _conv_sliced_impl(x, x2, w_src, A, B, K, src_ab, flip, ksize, stride, transp
         _chk(lib.dca_conv3d_x3_forward(_ptr(x), _ptr(wx), _ptr(y), _ptr(scale), _ptr(shift), _ptr(res_pre),
                                        _ptr(res_post), float(slope), N, A, B, Di, Hi, Wi, _stream()),
              "dca_conv3d_x3_forward")
+        return y, None
+    if _s2x2_eligible(x, x2, ksize, stride, transposed, A, B, scale, res_pre, slope):
+        wx = torch.empty((lib.dca_conv3d_s2x2_weight_bytes(A, B) // 2,), device=x.device, dtype=torch.int16)
+        xexps = _exps_cached(x)
+        if xexps is not None:
+            AMAX_STATS["tagged"] += 1
+            slots, nslots = None, 0
+        else:
+            slots, nslots = _slots_of(x)
+            xexps = torch.empty((A,), device=x.device, dtype=torch.int32)
+        _chk(lib.dca_conv3d_s2x2_prep_weight(_ptr(w_src), _ptr(wx), A, B, int(src_ab), int(flip), _ptr(slots), nslots,
+                                             _ptr(xexps), _stream()), "dca_conv3d_s2x2_prep_weight")
+        if slots is not None:
+            x._dca_exps = (xexps, _ver(x))
+        _chk(lib.dca_conv3d_s2x2_forward(_ptr(x), _ptr(xexps), _ptr(wx), _ptr(y), _ptr(res_post), N, A, B, Di, Hi, Wi,
+                                         _stream()), "dca_conv3d_s2x2_forward")
         return y, None
     if _dx3_eligible(x, x2, ksize, stride, transposed, A, B):
         def build_dx3():

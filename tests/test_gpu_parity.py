@@ -1366,3 +1366,54 @@ def test_prepack_plan_matches_per_call_packing():
     with plan.active():
         got2 = run()
     assert all(torch.equal(a, b) for a, b in zip(got2, ref2)) and not torch.equal(ref2[0], ref[0])
+
+
+S2X2_CASES = [
+    # N, cin, cout, fine dims
+    (2, 32, 64, (8, 16, 72)),       # cost_agg.conv1's layout, several tiles along every axis
+    (1, 30, 40, (7, 9, 36)),        # odd D / H, channel counts that fill neither a chunk of 4 nor a block of 64
+    (1, 64, 128, (4, 8, 12)),       # baseline hourglass widths: two output-channel blocks
+    (1, 32, 64, (5, 6, 132)),       # W spans three tiles, the last one partial
+]
+
+
+@pytest.mark.parametrize("case", S2X2_CASES, ids=[f"{c[1]}to{c[2]}@{'x'.join(map(str, c[3]))}" for c in S2X2_CASES])
+def test_conv3d_s2_f16x2_matches_fp64(case, monkeypatch):
+    """the stride-2 3x3x3 convolution on the f16x2 split (conv3d_s2_f16x2.hip) against fp64, per output channel, with input
+    channels spread over twelve orders of magnitude (per-channel scales) -- plain, with res_post, and as the backward-data of
+    the transposed convolution (the two launches of a training step it serves)"""
+    _, ops = _mods()
+    _family(monkeypatch, ops, "f16x2")
+    N, cin, cout, dims = case
+    spread = torch.logspace(-6, 6, cin).view(1, cin, 1, 1, 1)
+    x = seeded_tensor("s2x2.x", (N, cin) + dims) * spread
+    w = seeded_tensor("s2x2.w", (cout, cin, 3, 3, 3)) * 0.05 / spread.view(1, cin, 1, 1, 1)
+    yr = F.conv3d(x.double(), w.double(), None, 2, 1)
+    before = dict(ops.AMAX_STATS)
+    xg, wg = gpu(x), gpu(w)
+    y = ops._conv_sliced(xg, None, wg, cin, cout, 27, 0, 0, 3, 2, False)
+    assert ops._s2x2_eligible(xg, None, 3, 2, False, cin, cout, None, None, 1.0)
+    assert y.shape == yr.shape
+    scale = yr.abs().amax((0, 2, 3, 4)).clamp_min(1e-30)
+    err = ((y.cpu().double() - yr).abs().amax((0, 2, 3, 4)) / scale).max().item()
+    # the fp32 MFMA kernel on the same data, same measure
+    monkeypatch.setattr(ops, "CONV_S2_X2", False)
+    y32 = ops._conv_sliced(xg, None, wg, cin, cout, 27, 0, 0, 3, 2, False)
+    err32 = ((y32.cpu().double() - yr).abs().amax((0, 2, 3, 4)) / scale).max().item()
+    monkeypatch.setattr(ops, "CONV_S2_X2", True)
+    assert err <= 2 * err32 + 2e-7 and err <= 3e-6, (err, err32)     # fp32 MFMA itself: 1.3e-6 at 30 -> 40 channels
+    res = seeded_tensor("s2x2.r", tuple(yr.shape))
+    y2 = ops._conv_sliced(xg, None, wg, cin, cout, 27, 0, 0, 3, 2, False, res_post=gpu(res))
+    assert torch.equal(y2, y + gpu(res))
+    # backward-data of ConvTranspose3d(cout_t = cin, ...) over dy = x: the same operator, weight (cin_t = cout, cout_t = cin)
+    wt = seeded_tensor("s2x2.wt", (cout, cin, 3, 3, 3)) * 0.05 / spread.view(1, cin, 1, 1, 1)
+    z = torch.zeros((N, cout) + tuple(yr.shape[2:]), dtype=torch.float64, requires_grad=True)
+    if all(2 * o == i for o, i in zip(yr.shape[2:], dims)):
+        out = F.conv_transpose3d(z, wt.double(), None, 2, 1, 1)
+        gref, = torch.autograd.grad((out * x.double()).sum(), [z])
+        zg = gpu(torch.zeros((N, cout) + tuple(yr.shape[2:])), True)
+        outg = ops.conv3d(zg, gpu(wt), 2, True)
+        gg, = torch.autograd.grad((outg * xg).sum(), [zg])
+        sc = gref.abs().amax((0, 2, 3, 4)).clamp_min(1e-30)
+        e2 = ((gg.cpu().double() - gref).abs().amax((0, 2, 3, 4)) / sc).max().item()
+        assert e2 <= 3e-6, e2
