@@ -63,12 +63,17 @@ struct S2Args {
   int nTD, nTH, nTW;
   const int* xexps;          // scale exponent of every input channel (Cin ints)
   const int* ofo;            // behind the packed weight image: f_o of every output channel (blocks of 64)
+  int abl;                   // ablation switches (DCA_S2_ABL, tools/s2_time.py): 1 no staging loads, 2 no LDS stores, 4 no split
 };
 
 __device__ __forceinline__ void s2_split(float v, int e, _Float16& h, _Float16& l) {   // v 2^e = h + l (+ <= 2^-22 relative)
   const float u = ldexpf(v, e);
   h = (_Float16)u;
   l = (_Float16)(u - (float)h);
+}
+__device__ __forceinline__ void s2_split_abl(float v, int e, _Float16& h, _Float16& l, int abl) {
+  if (abl & 4) { h = (_Float16)v; l = h; return; }
+  s2_split(v, e, h, l);
 }
 
 // byte offset inside a term image of tap t's fragment relative to the lane's base (2 dl, 2 hl, slot w)
@@ -163,8 +168,8 @@ __global__ __launch_bounds__(512) void conv3s2_f16x2_kernel(S2Args a) {
       for (int j = 0; j < 4; ++j) {
         const float* c = (const float*)&rq[k][j];
         _Float16 h, l;
-        s2_split(c[va], e[j], h, l); hv[j] = h; lv[j] = l;
-        s2_split(c[vb], e[j], h, l); hv[4 + j] = h; lv[4 + j] = l;
+        s2_split_abl(c[va], e[j], h, l, a.abl); hv[j] = h; lv[j] = l;
+        s2_split_abl(c[vb], e[j], h, l, a.abl); hv[4 + j] = h; lv[4 + j] = l;
       }
       char* dst = img + (par ? B_PLANE + (2 * qq[k]) * 8 : (2 * qq[k] + 2) * 8);
       *(s2_f16x8*)dst = hv;
@@ -193,94 +198,103 @@ __global__ __launch_bounds__(512) void conv3s2_f16x2_kernel(S2Args a) {
     d0 = td * TD; h0 = th * TH; w0 = tw * TW;
   };
 
-  int n, d0, h0, w0;
-  decode(t_begin, n, d0, h0, w0);
-  {
-    const __amdgpu_buffer_rsrc_t xr = dca_rsrc(a.x + (long)n * sample, sample * 4);
-    load_quad(0, xr, d0, h0, w0, 0, 1);
-    load_quad(1, xr, d0, h0, w0, 0, 1);
-    load_edge(xr, d0, h0, w0, 0, 1);
-    load_A(0, 1);
-  }
+  // Three cursors walk the workgroup's chunk sequence (tile by tile, NC chunks each): cur = the chunk being computed, cur + 1 =
+  // the chunk whose data sits in the staging registers and is split + stored into the other buffer pair during cur, cur + 2 =
+  // the chunk whose loads are issued during cur, once the registers are free.  A global load thus has a whole chunk (~3 k
+  // cycles) to arrive; requested and consumed inside ONE chunk of 42 MFMAs per wave (the schedule of conv3d_f16x2.hip, whose
+  // chunks are 84 MFMAs long) the kernel waited for memory in every chunk: 67 k cycles per tile against 21.5 k of MFMAs.
+  struct Cursor { int tile, chunk, n, d0, h0, w0; };
+  auto advance = [&](Cursor& c) __attribute__((always_inline)) {
+    if (c.chunk + 1 < NC) {
+      ++c.chunk;
+    } else {
+      c.chunk = 0;
+      c.tile += t_step;
+      if (c.tile < t_end) decode(c.tile, c.n, c.d0, c.h0, c.w0);
+    }
+  };
+  auto load_all = [&](const Cursor& c, int part) __attribute__((always_inline)) {     // part 0: quad 0; 1: quad 1 + edge; 2: weights
+    const int on = (c.tile < t_end && !(a.abl & 1)) ? 1 : 0;
+    const __amdgpu_buffer_rsrc_t xr = dca_rsrc(a.x + (long)c.n * sample, sample * 4);
+    if (part == 0) load_quad(0, xr, c.d0, c.h0, c.w0, c.chunk, on);
+    if (part == 1) { load_quad(1, xr, c.d0, c.h0, c.w0, c.chunk, on); load_edge(xr, c.d0, c.h0, c.w0, c.chunk, on); }
+    if (part == 2) load_A(c.chunk, on);
+  };
+  Cursor cur{t_begin, 0, 0, 0, 0, 0}, st, ld;
+  decode(t_begin, cur.n, cur.d0, cur.h0, cur.w0);
+  load_all(cur, 0); load_all(cur, 1); load_all(cur, 2);
   __syncthreads();      // the exponent tables
   store_quad(0, 0, 0);
   store_quad(1, 0, 0);
   store_edge(0, 0);
   store_A(0);
+  st = cur;
+  advance(st);          // NC >= 2: the second chunk always exists
+  load_all(st, 0); load_all(st, 1); load_all(st, 2);
+  ld = st;
+  advance(ld);
   __syncthreads();
 
   const bool has_post = a.res_post != nullptr;
+  f32x16 acc[2];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
   int buf = 0;
 #pragma unroll 1
-  for (int tile = t_begin; tile < t_end; tile += t_step) {
-    const bool more_tiles = tile + t_step < t_end;
-    f32x16 acc[2];
+  for (; cur.tile < t_end; buf ^= 1) {
+    const char* ab = a_lds + buf * A_CHUNK + lane * 16;
+    const char* bb = b_lds + buf * B_BYTES + lanebase;
+    const bool st_on = st.tile < t_end && !(a.abl & 2);
+    s2_f16x8 fa[2][2][2], fb[2][2];      // [slot][channel block][term], [slot][term]
+    auto load_frag = [&](int s, int slot) __attribute__((always_inline)) {
+      const int oa = half ? s2_toff(4 * s + 2) : s2_toff(4 * s), ob = half ? s2_toff(4 * s + 3) : s2_toff(4 * s + 1);
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+      for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
-    int nn = n, nd0 = d0, nh0 = h0, nw0 = w0;
-    if (more_tiles) decode(tile + t_step, nn, nd0, nh0, nw0);
-
-#pragma unroll 1
-    for (int chunk = 0; chunk < NC; ++chunk, buf ^= 1) {
-      const bool last_chunk = chunk + 1 == NC;
-      const bool next_tile = last_chunk && more_tiles;
-      // the next chunk's (next tile's first chunk's) images are fetched while this chunk computes and written into the
-      // other buffer pair, which nobody reads before the barrier at the end of the chunk
-      const int s_n = next_tile ? nn : n, s_d0 = next_tile ? nd0 : d0, s_h0 = next_tile ? nh0 : h0, s_w0 = next_tile ? nw0 : w0;
-      const int s_chunk = next_tile ? 0 : chunk + 1, s_on = (!last_chunk || more_tiles) ? 1 : 0;
-      const __amdgpu_buffer_rsrc_t s_xr = dca_rsrc(a.x + (long)s_n * sample, sample * 4);
-      const char* ab = a_lds + buf * A_CHUNK + lane * 16;
-      const char* bb = b_lds + buf * B_BYTES + lanebase;
-      s2_f16x8 fa[2][2][2], fb[2][2];      // [slot][channel block][term], [slot][term]
-      auto load_frag = [&](int s, int slot) __attribute__((always_inline)) {
-        const int oa = half ? s2_toff(4 * s + 2) : s2_toff(4 * s), ob = half ? s2_toff(4 * s + 3) : s2_toff(4 * s + 1);
+        for (int term = 0; term < 2; ++term) fa[slot][cb][term] = *(const s2_f16x8*)(ab + ((s * 2 + cb) * 2 + term) * 1024);
+#pragma unroll
+      for (int term = 0; term < 2; ++term) {
+        const s2_f16x4 lo = *(const s2_f16x4*)(bb + term * B_TERM + oa), hi = *(const s2_f16x4*)(bb + term * B_TERM + ob);
+        fb[slot][term] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+    };
+    load_frag(0, 0);
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+      const int cs = s & 1;
+      if (s + 1 < NSTEP) load_frag(s + 1, cs ^ 1);
+      constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};      // smallest terms first
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-          for (int term = 0; term < 2; ++term) fa[slot][cb][term] = *(const s2_f16x8*)(ab + ((s * 2 + cb) * 2 + term) * 1024);
-#pragma unroll
-        for (int term = 0; term < 2; ++term) {
-          const s2_f16x4 lo = *(const s2_f16x4*)(bb + term * B_TERM + oa), hi = *(const s2_f16x4*)(bb + term * B_TERM + ob);
-          fb[slot][term] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        }
-      };
-      load_frag(0, 0);
-#pragma unroll
-      for (int s = 0; s < NSTEP; ++s) {
-        const int cur = s & 1;
-        if (s + 1 < NSTEP) load_frag(s + 1, cur ^ 1);
-        constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};      // smallest terms first
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb)
-            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][cb][PA[q]], fb[cur][PB[q]], acc[cb], 0, 0, 0);
-        // this K-step's share of the staging (compile-time schedule)
-        if (s == 0) load_quad(0, s_xr, s_d0, s_h0, s_w0, s_chunk, s_on);
-        if (s == 1) { load_quad(1, s_xr, s_d0, s_h0, s_w0, s_chunk, s_on); load_edge(s_xr, s_d0, s_h0, s_w0, s_chunk, s_on); }
-        if (s == 2) load_A(s_chunk, s_on);
-        if (s == 3) store_quad(0, s_chunk, buf ^ 1);
-        if (s == 4) store_quad(1, s_chunk, buf ^ 1);
-        if (s == 5) { store_edge(s_chunk, buf ^ 1); store_A(buf ^ 1); }
-        if (s + 1 < NSTEP) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // two LDS reads of the next K-step's fragments
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cs][cb][PA[q]], fb[cs][PB[q]], acc[cb], 0, 0, 0);
+      // this K-step's share of the staging (compile-time schedule): the registers' chunk (cur + 1) goes to LDS, then the
+      // registers are refilled with chunk cur + 2
+      if (st_on) {
+        if (s == 0) store_quad(0, st.chunk, buf ^ 1);
+        if (s == 1) store_quad(1, st.chunk, buf ^ 1);
+        if (s == 2) { store_edge(st.chunk, buf ^ 1); store_A(buf ^ 1); }
       }
-      if (!last_chunk) __syncthreads();
+      if (s == 3) load_all(ld, 0);
+      if (s == 4) load_all(ld, 1);
+      if (s == 5) load_all(ld, 2);
+      if (s + 1 < NSTEP) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // two LDS reads of the next K-step's fragments
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-
-    // epilogue: y = acc 2^-f_o [+ res_post]; a register = one output channel at the 32 consecutive w of the wave's row
-    {
-      const __amdgpu_buffer_rsrc_t yr = dca_rsrc(a.y + (long)n * osample, osample * 4);
-      const __amdgpu_buffer_rsrc_t qr = dca_rsrc((has_post ? a.res_post : a.y) + (long)n * osample, osample * 4);
-      const int d = d0 + dl, h = h0 + hl, w = w0 + l31;
+    if (cur.chunk + 1 == NC) {
+      // epilogue: y = acc 2^-f_o [+ res_post]; a register = one output channel at the 32 consecutive w of the wave's row
+      const __amdgpu_buffer_rsrc_t yr = dca_rsrc(a.y + (long)cur.n * osample, osample * 4);
+      const __amdgpu_buffer_rsrc_t qr = dca_rsrc((has_post ? a.res_post : a.y) + (long)cur.n * osample, osample * 4);
+      const int d = cur.d0 + dl, h = cur.h0 + hl, w = cur.w0 + l31;
       const int ok = (int)(d < a.Do) & (int)(h < a.Ho) & (int)(w < a.Wo);
       const int vbase = ((d * a.Ho + h) * a.Wo + w) * 4;
 #pragma unroll
@@ -292,11 +306,14 @@ __global__ __launch_bounds__(512) void conv3s2_f16x2_kernel(S2Args a) {
           float v = ldexpf(acc[cb][r], -fo_lds[cl]);
           if (has_post) v += dca_bload1(qr, vbase + co * ostride * 4, okc);
           dca_bstore1(yr, v, vbase + co * ostride * 4, okc);
+          acc[cb][r] = 0.f;
         }
       }
     }
-    __syncthreads();     // (the last chunk's barrier: the next tile's first images are complete, this tile's are free)
-    n = nn; d0 = nd0; h0 = nh0; w0 = nw0;
+    __syncthreads();     // chunk cur + 1's images are complete, chunk cur's are free
+    cur = st;
+    st = ld;
+    advance(ld);
   }
 }
 
@@ -407,7 +424,7 @@ extern "C" int dca_conv3d_s2x2_prep_weight(const float* w, void* wx, int A, int 
 // aligned, y (N, Cout, (Di+1)/2, (Hi+1)/2, (Wi+1)/2); xexps / wx from dca_conv3d_s2x2_prep_weight for THIS operand.
 extern "C" int dca_conv3d_s2x2_forward(const float* x, const int* xexps, const void* wx, float* y, const float* res_post, int N,
                                        int Cin, int Cout, int Di, int Hi, int Wi, hipStream_t stream) {
-  DCA_REQUIRE(x && xexps && wx && y && N > 0 && Cin > 0 && Cin <= MAX_CIN && Cout > 0 && Di > 0 && Hi > 0 && Wi > 0);
+  DCA_REQUIRE(x && xexps && wx && y && N > 0 && Cin > 4 && Cin <= MAX_CIN && Cout > 0 && Di > 0 && Hi > 0 && Wi > 0);   // >= 2 chunks: the staging runs two chunks ahead
   DCA_REQUIRE(Wi % 4 == 0 && ((((uintptr_t)x) | ((uintptr_t)wx)) & 15) == 0);
   S2Args a;
   a.x = x; a.wx = (const unsigned short*)wx; a.y = y; a.res_post = res_post;
@@ -417,6 +434,10 @@ extern "C" int dca_conv3d_s2x2_forward(const float* x, const int* xexps, const v
   DCA_REQUIRE((long)(Cin + 3) * Di * Hi * Wi * 4 < 0x7ffffff0L && (long)(Cout + 63) * a.Do * a.Ho * a.Wo * 4 < 0x7ffffff0L);
   a.nTD = cdiv(a.Do, TD); a.nTH = cdiv(a.Ho, TH); a.nTW = cdiv(a.Wo, TW);
   a.xexps = xexps;
+  {
+    static const int abl = [] { const char* e = getenv("DCA_S2_ABL"); return e ? atoi(e) : 0; }();
+    a.abl = abl;
+  }
   const int cblks = (Cout + 63) / 64;
   a.ofo = (const int*)((const char*)wx + (long)cblks * a.NC4 * A_CHUNK);
   const long tiles = (long)N * a.nTD * a.nTH * a.nTW;

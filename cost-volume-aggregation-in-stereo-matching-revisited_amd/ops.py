@@ -436,7 +436,7 @@ def _s2x2_eligible(x, x2, ksize, stride, transposed, A, B, scale, res_pre, slope
     16-byte aligned input, enough tiles to fill the chip (small volumes stay on the fp32 MFMA kernel)"""
     if not (CONV_X2 and CONV_X3 and CONV_S2_X2) or ksize != 3 or stride != 2 or transposed or x2 is not None:
         return False
-    if scale is not None or res_pre is not None or slope != 1.0 or A > 256:
+    if scale is not None or res_pre is not None or slope != 1.0 or A > 256 or A <= 4:
         return False
     N, _, D, H, W = x.shape
     Do, Ho, Wo = (D + 1) // 2, (H + 1) // 2, (W + 1) // 2
