@@ -280,6 +280,70 @@ __global__ __launch_bounds__(256) void bn_apply_pack_kernel(const float* __restr
   }
 }
 
+// The same with FOUR voxels per lane (S % 4 == 0, 16-byte aligned tensors): 16-byte loads per channel, the fp32 copy as
+// 16-byte stores, the packed words of the four voxels as 64 contiguous bytes per term; used when residuals are read too
+// (dca_bn_apply_pack).
+__global__ __launch_bounds__(256) void bn_apply_pack4_kernel(const float* __restrict__ y, const float* __restrict__ stats,
+                                                             const int* __restrict__ zexps, char* __restrict__ zp, int N,
+                                                             int C, long S, long chunk_len, float slope,
+                                                             unsigned* __restrict__ ymax, const float* __restrict__ res_pre,
+                                                             const float* __restrict__ res_post, float* __restrict__ zf,
+                                                             unsigned* __restrict__ zmax) {
+  const int cg = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+  const long s0 = ch * chunk_len, s1 = min(S, s0 + chunk_len);
+  float mean[8], sc[8], sh[8], ym[8], zm[8];
+  int ex[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cg * 8 + j;
+    mean[j] = stats ? stats[c] : 0.f;
+    sc[j] = stats ? stats[2 * C + c] : 1.f;
+    sh[j] = stats ? stats[3 * C + c] : 0.f;
+    ex[j] = dca_coherent_loadi(zexps + c);
+    ym[j] = zm[j] = 0.f;
+  }
+  const long tb = px2_term_bytes(C, S);
+  for (int n = N - 1; n >= 0; --n) {   // descending: see bn_bwd_reduce_kernel
+    const long cb = ((long)n * C + cg * 8) * S;
+    char* zb = zp + (long)n * 2 * tb + (long)cg * S * 16;
+    for (long i = s0 + 4 * tid; i < s1; i += 1024) {
+      u16x8 hv[4], lv[4];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float4 v4 = *(const float4*)(y + cb + j * S + i);
+        float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f), q4 = p4;
+        if (res_pre) p4 = *(const float4*)(res_pre + cb + j * S + i);
+        if (res_post) q4 = *(const float4*)(res_post + cb + j * S + i);
+        const float v[4] = {v4.x, v4.y, v4.z, v4.w}, rp[4] = {p4.x, p4.y, p4.z, p4.w}, rq[4] = {q4.x, q4.y, q4.z, q4.w};
+        float zz[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ym[j] = fmaxf(ym[j], fabsf(v[e] - mean[j]));
+          zz[e] = act_apply(v[e] * sc[j] + sh[j] + rp[e], slope) + rq[e];
+          zm[j] = fmaxf(zm[j], fabsf(zz[e]));
+          unsigned short h, l;
+          px2_split(zz[e], ex[j], h, l);
+          hv[e][j] = h; lv[e][j] = l;
+        }
+        if (zf) *(float4*)(zf + cb + j * S + i) = make_float4(zz[0], zz[1], zz[2], zz[3]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        *(u16x8*)(zb + (i + e) * 16) = hv[e];
+        *(u16x8*)(zb + tb + (i + e) * 16) = lv[e];
+      }
+    }
+  }
+  if (ymax) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dca_cmax_put(ym[j], ymax + (long)(cg * 8 + j) * DCA_AMAX_CSLOTS + ch);
+  }
+  if (zmax) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dca_cmax_put(zm[j], zmax + (long)(cg * 8 + j) * DCA_AMAX_CSLOTS + ch);
+  }
+}
+
 // per-channel max |x| of an fp32 tensor into slots [c][ch] (the read pass for operands whose producer emits nothing)
 __global__ __launch_bounds__(256) void cmax_kernel(const float* __restrict__ x, int N, int C, long S, long chunk_len, int vec,
                                                    unsigned* __restrict__ slots) {
@@ -612,20 +676,22 @@ __global__ __launch_bounds__(256) void avgpool3d_fwd_tiled_kernel(const float* _
   y[((nc * Do + od) * Ho + oh) * (long)Wo + ow] = s * (1.0f / 27.0f);
 }
 
-// Backward with 16-byte stores for aligned outputs (Wi % 4 == 0): a thread produces 4 consecutive fine w of one row
-// from the <= 2 x 2 x 3 coarse gradients above them; per-element summation order as in the scalar kernel.
+// Backward with 16-byte stores for aligned outputs (Wi % 4 == 0): a thread produces the 2 x 2 x 4 fine block
+// (d in {2bd-1, 2bd}, h in {2bh-1, 2bh}, w = 4t..4t+3) from the 2 x 2 x 3 coarse gradients above it -- an odd fine index lies
+// under two coarse cells, an even one under one -- 12 gather loads per four 16-byte stores (round 2: 12 per store; the kernel
+// was bound by its load instructions, 478 us per batch-4 launch against a 330 us stream); per-element summation order as in
+// the scalar kernel (bitwise identical results).
 __global__ __launch_bounds__(256) void avgpool3d_bwd_vec_kernel(const float* __restrict__ gy, float* __restrict__ gx,
                                                                 const float* __restrict__ res, int Di, int Hi, int Wi, int Do,
                                                                 int Ho, int Wo) {
-  const long row = blockIdx.x;
-  const int d = (int)(row % Di);
-  const long nc = row / Di;
+  const int BD = Di / 2 + 1, BH = Hi / 2 + 1;
+  const int bd = (int)(blockIdx.x % BD);
+  const long nc = blockIdx.x / BD;
   const long plane = (long)Do * Ho * Wo;
   const __amdgpu_buffer_rsrc_t gr = dca_rsrc(gy + nc * plane, plane * 4);
-  const int WQ = Wi >> 2, HQ = Hi * WQ, end = min(HQ, ((int)blockIdx.y + 1) * 1024);
-  const int d0 = d >> 1, dn = d & 1;
+  const int WQ = Wi >> 2, HQ = BH * WQ, end = min(HQ, ((int)blockIdx.y + 1) * 1024);
   for (int i = blockIdx.y * 1024 + threadIdx.x; i < end; i += 256) {
-    const int h = i / WQ, t = i - h * WQ, h0 = h >> 1, hn = h & 1, c0 = 2 * t;   // fine w = 4t .. 4t+3, coarse c0 .. c0+2
+    const int bh = i / WQ, t = i - bh * WQ, c0 = 2 * t;   // fine w = 4t .. 4t+3, coarse c0 .. c0+2
     float g[2][2][3];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -633,28 +699,39 @@ __global__ __launch_bounds__(256) void avgpool3d_bwd_vec_kernel(const float* __r
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          const int od = d0 + a, oh = h0 + b, ow = c0 + c;
-          const int ok = (a <= dn) & (b <= hn) & (int)(od < Do) & (int)(oh < Ho) & (int)(ow < Wo);
+          const int od = bd - 1 + a, oh = bh - 1 + b, ow = c0 + c;
+          const int ok = (int)((unsigned)od < (unsigned)Do) & (int)((unsigned)oh < (unsigned)Ho) & (int)(ow < Wo);
           g[a][b][c] = dca_bload1(gr, ((od * Ho + oh) * Wo + ow) * 4, ok);
         }
-    float o[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {   // fine w = 4t + e: coarse {w >> 1, (w + 1) >> 1} = c0 + {e >> 1, (e + 1) >> 1}
-      float s = 0.f;
+    for (int pd = 0; pd < 2; ++pd) {        // pd = 0: fine d = 2bd - 1 (odd: coarse a = 0, 1); pd = 1: d = 2bd (even: a = 1)
+      const int d = 2 * bd - 1 + pd;
+      if ((unsigned)d >= (unsigned)Di) continue;
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int ph = 0; ph < 2; ++ph) {
+        const int h = 2 * bh - 1 + ph;
+        if ((unsigned)h >= (unsigned)Hi) continue;
+        float o[4];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          s += g[a][b][e >> 1];
-          s += (e & 1) ? g[a][b][(e + 1) >> 1] : 0.f;
+        for (int e = 0; e < 4; ++e) {   // fine w = 4t + e: coarse {w >> 1, (w + 1) >> 1} = c0 + {e >> 1, (e + 1) >> 1}
+          float s = 0.f;
+#pragma unroll
+          for (int a = pd; a < 2; ++a)
+#pragma unroll
+            for (int b = ph; b < 2; ++b) {
+              s += g[a][b][e >> 1];
+              s += (e & 1) ? g[a][b][(e + 1) >> 1] : 0.f;
+            }
+          o[e] = s * (1.0f / 27.0f);
         }
-      o[e] = s * (1.0f / 27.0f);
+        const long off = ((nc * Di + d) * Hi + h) * (long)Wi + 4 * t;
+        if (res) {   // + another gradient of the same input (ops._PoolFork): saves autograd's separate accumulation pass
+          const float4 r = *(const float4*)(res + off);
+          o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+        }
+        *(float4*)(gx + off) = make_float4(o[0], o[1], o[2], o[3]);
+      }
     }
-    if (res) {   // + another gradient of the same input (ops._PoolFork): saves autograd's separate accumulation pass
-      const float4 r = *(const float4*)(res + (row * Hi + h) * (long)Wi + 4 * t);
-      o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
-    }
-    *(float4*)(gx + (row * Hi + h) * (long)Wi + 4 * t) = make_float4(o[0], o[1], o[2], o[3]);
   }
 }
 
@@ -965,8 +1042,14 @@ extern "C" int dca_bn_apply_pack(const float* y, const float* stats, const int* 
   DCA_REQUIRE(stats != nullptr || (ymax == nullptr && slope == 1.f));
   int nchunk; long len;
   chunking(S, C / 8, &nchunk, &len);
-  hipLaunchKernelGGL(bn_apply_pack_kernel, dim3(nchunk, C / 8), dim3(256), 0, stream, y, stats, zexps, (char*)zp, N, C, S,
-                     len, slope, ymax, res_pre, res_post, zf, zmax);
+  const uintptr_t al = (uintptr_t)y | (uintptr_t)res_pre | (uintptr_t)res_post | (uintptr_t)zf;
+  // four voxels per lane pay when residual streams are read beside y (batch-4 layer shape, tools/bn_time.py: 631 vs 726 us with
+  // fp32 copy + one residual); without them the one-voxel form is faster (332 vs 449 us packed only, 563 vs 584 with the copy:
+  // its packed stores are contiguous per instruction, the four-voxel form's are 16 of every 64 bytes)
+  const bool four = (res_pre || res_post) && S % 4 == 0 && (al & 15) == 0;       // chunks are multiples of 1024
+  auto kern = four ? bn_apply_pack4_kernel : bn_apply_pack_kernel;
+  hipLaunchKernelGGL(kern, dim3(nchunk, C / 8), dim3(256), 0, stream, y, stats, zexps, (char*)zp, N, C, S, len, slope, ymax,
+                     res_pre, res_post, zf, zmax);
   return dca_launch_status();
 }
 
@@ -1045,8 +1128,8 @@ extern "C" int dca_avgpool3d_bwd(const float* gy, float* gx, const float* res, l
   const int Do = (Di + 1) / 2, Ho = (Hi + 1) / 2, Wo = (Wi + 1) / 2;
   DCA_REQUIRE((long)Di * Hi * Wi * 4 < 0x7ffffff0L && NC * Di < 0x7fffffffL);
   if (Wi % 4 == 0 && ((((uintptr_t)gx) | ((uintptr_t)res)) & 15) == 0) {
-    hipLaunchKernelGGL(avgpool3d_bwd_vec_kernel, dim3((unsigned)(NC * Di), cdiv((long)Hi * (Wi / 4), 1024)), dim3(256), 0,
-                       stream, gy, gx, res, Di, Hi, Wi, Do, Ho, Wo);
+    hipLaunchKernelGGL(avgpool3d_bwd_vec_kernel, dim3((unsigned)(NC * (Di / 2 + 1)), cdiv((long)(Hi / 2 + 1) * (Wi / 4), 1024)),
+                       dim3(256), 0, stream, gy, gx, res, Di, Hi, Wi, Do, Ho, Wo);
     return dca_launch_status();
   }
   hipLaunchKernelGGL(avgpool3d_bwd_kernel, dim3((unsigned)(NC * Di), cdiv((long)Hi * Wi, 1024)), dim3(256), 0, stream, gy,
