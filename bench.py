@@ -206,6 +206,14 @@ def kernel_roofline(device, dtype="f32"):
                           "split)", "wgrad3s2_f16x2", PEAK_BF16_MFMA_TFLOPS / 3.0,
                           lambda: ops._wgrad(x, xc2, gw2, 0, 32, 64, 3, 2, 32 * 27, 27),
                           2.0 * 27 * 32 * 64 * (d // 2) * (h // 2) * (w // 2)))
+        # the stride-2 convolution itself (cost_agg.conv1 forward, cost_agg.conv3 backward-data): 32 -> 64, 1/4 -> 1/8 res
+        if ops.CONV_X3 and ops.CONV_X2 and ops.CONV_S2_X2:
+            ws2 = torch.randn(64, 32, 3, 3, 3, device=device) * 0.05
+            ops._exps_of(x)       # in the network the exponents come with the tensor (its producer emits the maxima)
+            cases.append(("conv3s2_f16x2_kernel (3x3x3 stride-2 conv 32->64, 1/4 -> 1/8 res; 3-product f16 split, weights packed "
+                          "per launch)", "conv3s2_f16x2", PEAK_BF16_MFMA_TFLOPS / 3.0,
+                          lambda: ops._conv_sliced(x, None, ws2, 32, 64, 27, 0, 0, 3, 2, False),
+                          2.0 * 27 * 32 * 64 * (d // 2) * (h // 2) * (w // 2)))
         # the transposed convolution of the cva blocks (64 -> 32, 1/8 -> 1/4 res), same 6-product split: its own FLOP count
         if ops.CONV_X3 and ops.DECONV_X3:
             xc = torch.randn(1, 64, d // 2, h // 2, w // 2, device=device)
@@ -255,7 +263,7 @@ def kernel_roofline(device, dtype="f32"):
                 out[name]["algorithmic_bytes"] = lp_bytes
                 out[name]["hbm_view"] = {"achieved": round(lp_bytes / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
                                          "unit": "GB/s", "frac": round(lp_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
-            if key in ("conv3_f16x2", "wgrad3_f16x2", "wgrad3s2_f16x2", "conv3_f16x2_px2", "wgrad3_f16x2_px2"):
+            if key in ("conv3_f16x2", "wgrad3_f16x2", "wgrad3s2_f16x2", "conv3_f16x2_px2", "wgrad3_f16x2_px2", "conv3s2_f16x2"):
                 out[name]["peak_note"] = "dense f16 MFMA peak (2500) / 3 products per fp32 product"
                 out[name]["executed_f16"] = {"achieved": round(3 * tf, 1), "peak": PEAK_BF16_MFMA_TFLOPS,
                                              "unit": "TFLOP/s", "frac": round(3 * tf / PEAK_BF16_MFMA_TFLOPS, 4)}

@@ -2,10 +2,10 @@
 
 Collect (on the GPU box; separate --pmc passes -- FETCH_SIZE and WRITE_SIZE do not fit one pass, and gpurun refuses
 --pmc together with the trace domains):
-    tools/pmc_collect.sh          # three rocprofv3 passes over this script -> gpurun_out/pmc_r03_{fetch,write,sq}
+    tools/pmc_collect.sh          # three rocprofv3 passes over this script -> gpurun_out/pmc_r03b_{fetch,write,sq}
 then -- in the development container, where the snapshot's commit is known (the GPU box has no .git) -- fold them into
 profiles/r03_pmc_traffic.json (the file bench.py reads), with the commit they were taken at:
-    python tools/pmc_kernels.py --summarise gpurun_out/pmc_r03_fetch gpurun_out/pmc_r03_write gpurun_out/pmc_r03_sq
+    python tools/pmc_kernels.py --summarise gpurun_out/pmc_r03b_fetch gpurun_out/pmc_r03b_write gpurun_out/pmc_r03b_sq
 
 HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB: gfx950's FETCH_SIZE tallies 128-byte requests at 64 bytes
 (MI355X_MICROARCH.md, HBM section; exact for 16-byte-per-lane streams, other access widths are uncalibrated).
@@ -28,6 +28,7 @@ KEYS = {   # substring of the kernel name -> (key, algorithmic bytes per launch)
     "wgrad3_f16x2_kernel<true, true>": ("wgrad3_f16x2_px2", 2 * 32 * V4 * 4 + 27 * 32 * 32 * 4),
     "wgrad3_f16x2_kernel<false, false>": ("wgrad3_f16x2", 2 * 32 * V4 * 4 + 27 * 32 * 32 * 4),
     "wgrad3s2_f16x2_kernel": ("wgrad3s2_f16x2", 4 * (32 * V4 + 64 * V4 // 8) + 27 * 32 * 64 * 4),
+    "conv3s2_f16x2_kernel": ("conv3s2_f16x2", 4 * (32 * V4 + 64 * V4 // 8) + 27 * 32 * 64 * 4),
     "::conv3_bf16x3_kernel": ("conv3_bf16x3", 2 * 32 * V4 * 4 + 27 * 32 * 32 * 4),
     "wgrad3_bf16x3_kernel": ("wgrad3_bf16x3", 2 * 32 * V4 * 4 + 27 * 32 * 32 * 4),
     "conv3_mfma_kernel<1, 1, 8, 4, 8, 16, true": ("conv3_mfma", 2 * 32 * V4 * 4 + 27 * 32 * 32 * 4),
