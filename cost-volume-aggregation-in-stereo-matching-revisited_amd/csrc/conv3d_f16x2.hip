@@ -27,14 +27,16 @@
 // Reference operators served: nn.Conv3d(k=3, s=1, p=1) of convbn_3d (models/submodule.py:121-124) in dres0/dres1,
 // Multi_Aggregation and the cva blocks (models/augment/cva.py:13-55), and their backward-data.
 //
-// Work decomposition (that of conv3d_bf16x3.hip): one workgroup (8 waves) per 4 x 8 x 16 output tile (512 voxels = 16
-// MFMA column tiles, two per wave) and 32 output channels; one workgroup per CU, two waves per SIMD.  Input channels go
-// through LDS in chunks of 16 (one MFMA K): the 6 x 10 x 18 halo tile of the chunk, pre-split into two f16 images laid out
-// [term][k half][voxel][8 f16] so that a lane's B fragment (8 consecutive k of its voxel) is one ds_read_b128 and 16
-// consecutive lanes read 256 contiguous bytes.  The weights arrive pre-scaled, pre-split and pre-swizzled into MFMA A
-// fragments (x2_prep_weight_kernel) and stream through a double-buffered LDS slab of 9 taps (one kd plane) per phase, so
-// a channel chunk is three phases of 54 MFMAs per wave with one barrier each; the next slab / next halo tile are fetched
-// into registers (hardware-predicated buffer loads) while the current phase's MFMAs run.
+// Work decomposition: one persistent workgroup (8 waves) per CU; a tile is 4 x 8 x 16 output voxels (512 = 16 MFMA column
+// tiles, two per wave) times 32 output channels.  Input channels go through LDS in chunks of EIGHT: the K = 16 of one MFMA is
+// 8 channels x 2 taps, so a chunk is 14 tap pairs (the 28th tap has zero weights) = 84 MFMAs per wave behind ONE barrier
+// (round 2: 16-channel chunks in three phases of 54 MFMAs with a barrier each and two more around the halo store).  Per
+// chunk LDS holds the 6 x 10 x 18 halo tile, pre-split into two f16 term images [term][voxel][8 f16] (34.5 KB: a lane's B
+// fragment -- its voxel's 8 channels at the pair's tap of its wave half -- is one ds_read_b128), and the chunk's weight
+// fragments (28 KB, pre-scaled, pre-split and pre-swizzled by x2_prep_weight_kernel); both are double buffered (126 KB), so the
+// loads, the [split and] LDS stores of the next chunk and the MFMAs of this one need no ordering among themselves.  The
+// staging steps sit at compile-time positions between the tap pairs (one global load or one LDS store per pair): issued as a
+// burst they held the matrix pipe for 1-2.4 k cycles per chunk (s_memtime stamps, tools/x2_stamps.py).
 #include "dca_common.h"
 #include "bn_fused_stats.h"
 #include <type_traits>

@@ -25,8 +25,15 @@
 //
 // Staging (fp32 x, Wi % 4 == 0): a fine halo row is one edge voxel + 16 aligned quads; 720 quad items (4 voxels x 4 channels
 // = four 16-byte loads) and 45 edge items per chunk, at most two quad items per thread; scaled by 2^xexps[channel], split and
-// written as four ds_write_b128 per quad item.  The loads ride behind the MFMAs of K-steps 0-2, the splits and stores behind
+// written as four ds_write_b128 per quad item.  The staging runs TWO chunks ahead (three cursors, see the kernel): during chunk
+// c the registers' data (chunk c + 1) is split and stored behind K-steps 0-2 and the loads of chunk c + 2 are issued behind
 // K-steps 3-5 (compile-time schedule, as in conv3d_f16x2.hip).
+//
+// Measured (tools/s2_time.py, 32 -> 64 at 48x136x240, batch 4): 0.45 ms against 0.87 ms for the fp32 MFMA kernel.  Ablations
+// (DCA_S2_ABL): without staging loads 0.34, without split + LDS stores 0.38, with neither 0.24 ms -- the MFMAs alone need 0.14 ms
+// at the clock held.  The kernel moves 1 KB of LDS reads per MFMA (a 32 x 32 accumulator tile reuses nothing) and 78 KB of LDS
+// stores per chunk of 42 MFMAs per wave (the weights' 28 KB are re-staged for every tile): LDS traffic, not the matrix pipe,
+// sets its speed.
 #include "dca_common.h"
 
 typedef _Float16 s2_f16x8 __attribute__((ext_vector_type(8)));

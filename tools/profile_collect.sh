@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 kernel-trace passes of bench.py for one profiles/ set (run on the GPU box from the repo root):
 #     bash tools/profile_collect.sh r02_c
-# writes gpurun_out/<set>_{fwdbwd_b1,fwd_f32,fwd_bf16}_{kernel_stats.csv,step_breakdown.txt}
+# writes gpurun_out/<set>_{fwdbwd_b1,fwd_f32,fwd_bf16,fwd_fp16}_{kernel_stats.csv,step_breakdown.txt}
 set -e
 SET=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -16,3 +16,4 @@ run() {  # name, bench args...
 run fwdbwd_b1 --batch 1 --steps 8 --warmup 3
 run fwd_f32 --mode fwd --steps 20 --warmup 5
 run fwd_bf16 --mode fwd --dtype bf16 --steps 20 --warmup 5
+run fwd_fp16 --mode fwd --dtype fp16 --steps 20 --warmup 5
