@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(HERE, "libdca_hip.so")
 
 _p, _i, _l, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double
 
-ABI_VERSION = 15  # == DCA_ABI_VERSION of include/dca_hip.h
+ABI_VERSION = 16  # == DCA_ABI_VERSION of include/dca_hip.h
 
 # name -> (restype, argtypes); mirrors include/dca_hip.h one to one
 SIGNATURES = {
@@ -57,6 +57,7 @@ SIGNATURES = {
     "dca_conv3d_wgrad_x2": (_i, [_p, _i, _p, _p, _i, _p, _p, _p] + [_i] * 6 + [_l, _l, _p]),
     "dca_conv3d_wgrad": (_i, [_p, _p, _p, _p] + [_i] * 11 + [_l, _l, _p]),
     "dca_conv3d_c1_gather": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "dca_conv3d_c1_wgrad": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "dca_conv3d_c1_expand": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "dca_conv3d_c1_bwd_data": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "dca_bn_num_chunks": (_i, [_i, _l]),

@@ -211,6 +211,11 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(WgArgs a) {
 // 1x1x1: dW[cy][cx] = sum_v dy[cy][v] x[cx][v]; tile = 256 voxels, each wave contracts 64 of them.  HBM-bound (reads x
 // and dy once): two workgroups per CU, and on aligned inputs the next tile's 2 x 32 KB are fetched into registers by
 // predicated buffer loads while the current tile's MFMAs run.
+// TAPS (the 32 -> 1 logit heads, conv3d_c1.hip): dy is the ONE-channel gradient (N, 1, D, H, W) and "channel" t < 27 of the dy
+// operand is the tap-shifted view G[t][v] = dy[v - offset(t)] (zero outside the volume), built while the tile is fetched --
+// the 27-plane tensor dca_conv3d_c1_expand materialises (680 MB written and read back per batch-4 head) never exists; dy
+// itself (25 MB) is served by the caches.  Pipelined path only (W % 4 == 0: a quad of voxels lies in one row).
+template <bool TAPS>
 __global__ __launch_bounds__(256, 2) void wgrad1_kernel(WgArgs a) {
   constexpr int NV = 256, P = NV + 1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -228,8 +233,13 @@ __global__ __launch_bounds__(256, 2) void wgrad1_kernel(WgArgs a) {
   const bool pipelined = a.vecx && a.small_offsets;   // 32-bit byte offsets inside the whole tensors
   if (pipelined) {
     const __amdgpu_buffer_rsrc_t xr = dca_rsrc(a.x, (long)a.N * a.Cx * DHW * 4);
-    const __amdgpu_buffer_rsrc_t yr = dca_rsrc(a.dy, (long)a.N * a.Cy * DHW * 4);
-    float4 rx[8], ry[8];
+    const __amdgpu_buffer_rsrc_t yr = dca_rsrc(a.dy, (long)a.N * (TAPS ? 1 : a.Cy) * DHW * 4);
+    // TAPS: a thread's dy items are (row r = (od, oh) of the 3 x 3 tap rows, quad q): the aligned quad M of dy at the shifted
+    // row plus its left and right neighbours give the quads of the row's three taps (ow = -1, 0, +1): 3 loads per 3 taps
+    // (first version: one item per tap, four 4-byte loads for every ow != 0 -- 24 load instructions per thread and tile
+    // against 8 for x, 616 us per batch-4 head where x streams in 170)
+    float4 rx[8], ry[TAPS ? 3 : 8];
+    float rl[TAPS ? 3 : 1], rr[TAPS ? 3 : 1];
     auto load_regs = [&](long tile) __attribute__((always_inline)) {
       const int n = (int)(tile / tiles_per_n);
       const int v0 = (int)((tile % tiles_per_n) * NV);
@@ -238,9 +248,27 @@ __global__ __launch_bounds__(256, 2) void wgrad1_kernel(WgArgs a) {
         const int it = tid + 256 * k, q = it & 63, c = it >> 6;
         const int v = v0 + 4 * q, ok = (int)(v < DHW);
         rx[k] = dca_bload4(xr, (int)((((long)n * a.Cx + cx0 + c) * DHW + v) * 4), ok & (int)(cx0 + c < a.Cx));
-        ry[k] = dca_bload4(yr, (int)((((long)n * a.Cy + cy0 + c) * DHW + v) * 4), ok & (int)(cy0 + c < a.Cy));
+        if constexpr (!TAPS)
+          ry[k] = dca_bload4(yr, (int)((((long)n * a.Cy + cy0 + c) * DHW + v) * 4), ok & (int)(cy0 + c < a.Cy));
+      }
+      if constexpr (TAPS) {
+        const int vq = v0 + 4 * (tid & 63);                      // the thread's quad of voxels: the same for its 3 items
+        const int qw = vq % a.Wo, t = vq / a.Wo, qh = t % a.Ho, qd = t / a.Ho;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int r = (tid >> 6) + 4 * k, od = r / 3 - 1, oh = r % 3 - 1;      // wave-uniform
+          const int dd = qd - od, hh = qh - oh;
+          const int okr = (int)(vq < DHW) & (int)(r < 9) & (int)((unsigned)dd < (unsigned)a.Do) & (int)((unsigned)hh < (unsigned)a.Ho);
+          const int base = (int)(((long)n * DHW + ((long)dd * a.Ho + hh) * a.Wo + qw) * 4);
+          ry[k] = dca_bload4(yr, base, okr);
+          rl[k] = dca_bload1(yr, base - 4, okr & (int)(qw > 0));
+          rr[k] = dca_bload1(yr, base + 16, okr & (int)(qw + 4 < a.Wo));
+        }
       }
     };
+    if constexpr (TAPS) {      // "channels" 27..31 of the dy operand do not exist: zero once, never written afterwards
+      for (int i = tid; i < 5 * P; i += 256) ys[27 * P + i] = 0.f;
+    }
     if ((long)blockIdx.x < ntile) load_regs(blockIdx.x);
     for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
       __syncthreads();
@@ -248,9 +276,23 @@ __global__ __launch_bounds__(256, 2) void wgrad1_kernel(WgArgs a) {
       for (int k = 0; k < 8; ++k) {
         const int it = tid + 256 * k, q = it & 63, c = it >> 6;
         float* dx = xs + c * P + 4 * q;
-        float* dyp = ys + c * P + 4 * q;
         dx[0] = rx[k].x; dx[1] = rx[k].y; dx[2] = rx[k].z; dx[3] = rx[k].w;
-        dyp[0] = ry[k].x; dyp[1] = ry[k].y; dyp[2] = ry[k].z; dyp[3] = ry[k].w;
+        if constexpr (!TAPS) {
+          float* dyp = ys + c * P + 4 * q;
+          dyp[0] = ry[k].x; dyp[1] = ry[k].y; dyp[2] = ry[k].z; dyp[3] = ry[k].w;
+        }
+      }
+      if constexpr (TAPS) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int r = (tid >> 6) + 4 * k, q = tid & 63;
+          if (r < 9) {      // tap 3r (ow = -1): dy[w + 1 ..]; tap 3r + 1: the quad itself; tap 3r + 2 (ow = +1): dy[w - 1 ..]
+            float* e0 = ys + (3 * r) * P + 4 * q;
+            e0[0] = ry[k].y; e0[1] = ry[k].z; e0[2] = ry[k].w; e0[3] = rr[k];
+            e0[P] = ry[k].x; e0[P + 1] = ry[k].y; e0[P + 2] = ry[k].z; e0[P + 3] = ry[k].w;
+            e0[2 * P] = rl[k]; e0[2 * P + 1] = ry[k].x; e0[2 * P + 2] = ry[k].y; e0[2 * P + 3] = ry[k].z;
+          }
+        }
       }
       __syncthreads();
       if (tile + gridDim.x < ntile) load_regs(tile + gridDim.x);
@@ -391,9 +433,9 @@ extern "C" int dca_conv3d_wgrad(const float* x, const float* dy, float* part, fl
     const long DHW = (long)Do * Ho * Wo;
     a.vecx = a.vecy = (DHW % 4 == 0) && ((((uintptr_t)x | (uintptr_t)dy) & 15) == 0);
     const size_t lds = (size_t)2 * 32 * 257 * 4;
-    hipError_t e = hipFuncSetAttribute((const void*)wgrad1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad1_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(wgrad1_kernel, grid, dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(wgrad1_kernel<false>, grid, dim3(256), lds, stream, a);
   } else {
     a.vecx = (Wi % 4 == 0) && (((uintptr_t)x & 15) == 0);
     a.vecy = (Wo % 4 == 0) && (((uintptr_t)dy & 15) == 0);
@@ -421,5 +463,36 @@ extern "C" int dca_conv3d_wgrad(const float* x, const float* dy, float* part, fl
   if (st) return st;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((long)nCT * K * 1024, 64)), dim3(1024), 0, stream, part, dw, nblk,
                      a.nCxT, nCT, K, Cy, Cx, s_cy, s_cx);
+  return dca_launch_status();
+}
+
+// Weight gradient of the 32 -> 1 logit heads (nn.Conv3d(C, 1, 3, padding=1, bias=False): `classif*.2`
+// models/gwcnet_dca_g.py:154-168, `classify.2` models/augment/cva.py:51-53) without the tap-expanded gradient tensor:
+// dw[ci * 27 + tap] = sum_{n, v} x[n][ci][v] dy[n][0][v - offset(tap)].  x (N, C, D, H, W), dy (N, 1, D, H, W), 16-byte aligned,
+// W % 4 == 0, N*C*D*H*W*4 < 2^31 (hipErrorInvalidValue otherwise: callers use dca_conv3d_c1_expand + dca_conv3d_wgrad);
+// part = dca_conv3d_wgrad_workspace(N, C, 27, D, H, W, 1, 1) floats.
+extern "C" int dca_conv3d_c1_wgrad(const float* x, const float* dy, float* part, float* dw, int N, int C, int D, int H,
+                                   int W, hipStream_t stream) {
+  DCA_REQUIRE(x && dy && part && dw && N > 0 && C > 0 && D > 0 && H > 0 && W > 0 && W % 4 == 0);
+  DCA_REQUIRE((((uintptr_t)x | (uintptr_t)dy) & 15) == 0 && (long)N * C * D * H * W * 4 < 0x7ffffff0L);
+  WgArgs a;
+  a.x = x; a.dy = dy; a.part = part; a.N = N; a.Cx = C; a.Cy = 27;
+  a.Di = a.Do = D; a.Hi = a.Ho = H; a.Wi = a.Wo = W;
+  long ntiles;
+  wg_geometry(1, 1, N, D, H, W, &a.nTD, &a.nTH, &a.nTW, &ntiles);
+  DCA_REQUIRE(ntiles < (1L << 31));
+  a.ntiles = (int)ntiles;
+  a.small_offsets = 1; a.vecx = a.vecy = 1;
+  a.nCxT = cdiv(C, 32);
+  const int nCT = a.nCxT;
+  const int nblk = wg_workers((int)(ntiles < 65535 ? ntiles : 65535), nCT, 2);
+  const size_t lds = (size_t)2 * 32 * 257 * 4;
+  hipError_t e = hipFuncSetAttribute((const void*)wgrad1_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(wgrad1_kernel<true>, dim3(nblk, nCT), dim3(256), lds, stream, a);
+  int st = dca_launch_status();
+  if (st) return st;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((long)nCT * 1024, 64)), dim3(1024), 0, stream, part, dw, nblk, a.nCxT,
+                     nCT, 1, 27, C, 1L, 27L);
   return dca_launch_status();
 }

@@ -297,6 +297,7 @@ CONV_X3 = _CONV_MODE != "fp32"
 CONV_X2 = _CONV_MODE == "x2"
 WGRAD_S2_X2 = os.environ.get("DCA_WGRAD_S2", "x2") != "fp32"   # stride-2 / transposed weight gradient on the f16x2 split (A/B)
 DECONV_X3 = os.environ.get("DCA_DECONV", "x3") != "fp32"
+C1_WGRAD_FUSED = os.environ.get("DCA_C1_WGRAD", "fused") != "expand"   # logit heads: weight gradient without the 27-plane tensor (A/B)
 CONV_S2_X2 = os.environ.get("DCA_CONV_S2", "x2") != "fp32"     # the stride-2 convolution itself on the f16x2 split (A/B)
 BN_FUSE = os.environ.get("DCA_BN_FUSE", "1") != "0"        # BatchNorm batch statistics from the conv epilogue (training)   # the transposed-convolution member of the family alone (A/B timing)
 _X3_MIN_WORKGROUPS = 1
@@ -728,10 +729,18 @@ class _Conv3dC1(torch.autograd.Function):
                 _chk(lib.dca_conv3d_c1_bwd_data(_ptr(dy), _ptr(weight), _ptr(gx), N, C, D, H, W, _stream()),
                      "dca_conv3d_c1_bwd_data")
             if ctx.needs_input_grad[1]:
-                G = torch.empty((N, 27, D, H, W), device=x.device, dtype=torch.float32)
-                _chk(lib.dca_conv3d_c1_expand(_ptr(dy), _ptr(G), N, D, H, W, _stream()), "dca_conv3d_c1_expand")
                 gw = torch.empty_like(weight)
-                _wgrad(x, G, gw, 0, C, 27, 1, 1, 1, 27)                          # dw[ci*27 + tap]
+                if (C1_WGRAD_FUSED and W % 4 == 0 and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0
+                        and x.numel() * 4 < 0x7ffffff0):
+                    # the tap-shifted views of dy are built inside the weight-gradient kernel: no 27-plane tensor
+                    nws = lib.dca_conv3d_wgrad_workspace(N, C, 27, D, H, W, 1, 1)
+                    part = torch.empty((nws,), device=x.device, dtype=torch.float32)
+                    _chk(lib.dca_conv3d_c1_wgrad(_ptr(x), _ptr(dy), _ptr(part), _ptr(gw), N, C, D, H, W, _stream()),
+                         "dca_conv3d_c1_wgrad")
+                else:
+                    G = torch.empty((N, 27, D, H, W), device=x.device, dtype=torch.float32)
+                    _chk(lib.dca_conv3d_c1_expand(_ptr(dy), _ptr(G), N, D, H, W, _stream()), "dca_conv3d_c1_expand")
+                    _wgrad(x, G, gw, 0, C, 27, 1, 1, 1, 27)                      # dw[ci*27 + tap]
         return gx, gw
 
 

@@ -23,7 +23,7 @@ extern "C" {
 
 /* Bumped whenever an argument list below changes; the ctypes loader (_lib.py) refuses a library built from another
  * version of this header. */
-#define DCA_ABI_VERSION 15
+#define DCA_ABI_VERSION 16
 int dca_abi_version(void);
 
 /* storage types of the reduced-precision inference path (0 = fp32) */
@@ -256,6 +256,11 @@ int dca_conv3d_wgrad_x2(const void* x, int x_packed, const int* xexps, const voi
  *   wgrad:   G (N,27,D,H,W) = dca_conv3d_c1_expand(dy);  dW = dca_conv3d_wgrad(x, G, ksize 1, s_cy 1, s_cx 27)
  *   bwd_data: dy (N,1,..) -> dx (N,C,..) directly. */
 int dca_conv3d_c1_gather(const float* T, float* y, int N, int D, int H, int W, hipStream_t stream);
+/* wgrad without the expanded tensor (round 3): dw[ci*27 + tap] = sum x[ci][v] dy[v - offset(tap)], the tap-shifted views of dy
+ * are built while the tiles are fetched.  W % 4 == 0, 16-byte aligned x / dy, N*C*D*H*W*4 < 2^31 (hipErrorInvalidValue
+ * otherwise: use the expand form); part = dca_conv3d_wgrad_workspace(N, C, 27, D, H, W, 1, 1) floats. */
+int dca_conv3d_c1_wgrad(const float* x, const float* dy, float* part, float* dw, int N, int C, int D, int H, int W,
+                        hipStream_t stream);
 int dca_conv3d_c1_expand(const float* dy, float* G, int N, int D, int H, int W, hipStream_t stream);
 int dca_conv3d_c1_bwd_data(const float* dy, const float* w, float* dx, int N, int C, int D, int H, int W,
                            hipStream_t stream);

@@ -1417,3 +1417,23 @@ def test_conv3d_s2_f16x2_matches_fp64(case, monkeypatch):
         sc = gref.abs().amax((0, 2, 3, 4)).clamp_min(1e-30)
         e2 = ((gg.cpu().double() - gref).abs().amax((0, 2, 3, 4)) / sc).max().item()
         assert e2 <= 3e-6, e2
+
+
+def test_c1_head_wgrad_without_expanded_tensor_is_bitwise(monkeypatch):
+    """logit heads (Conv3d(32, 1, 3)): the weight gradient built from tap-shifted views of dy inside the kernel
+    (dca_conv3d_c1_wgrad) equals the expand + 1x1x1 form bit for bit (same tiles, same operands), and fp64 to 1e-5"""
+    _, ops = _mods()
+    for N, C, dims in ((2, 32, (5, 7, 36)), (1, 64, (3, 9, 260))):
+        x = seeded_tensor("c1w.x", (N, C) + dims); w = seeded_tensor("c1w.w", (1, C, 3, 3, 3)) * 0.05
+        gy = seeded_tensor("c1w.g", (N, 1) + dims)
+        out = {}
+        for fused in (True, False):
+            monkeypatch.setattr(ops, "C1_WGRAD_FUSED", fused)
+            xg, wg = gpu(x, True), gpu(w, True)
+            y = ops.conv3d(xg, wg, 1, False)
+            out[fused] = torch.autograd.grad((y * gpu(gy)).sum(), [wg])[0]
+        assert torch.equal(out[True], out[False])
+        xd, wd = x.double(), w.double().requires_grad_()
+        ref, = torch.autograd.grad((F.conv3d(xd, wd, None, 1, 1) * gy.double()).sum(), [wd])
+        err = (out[True].cpu().double() - ref).abs().max().item()
+        assert err <= 1e-5 * ref.abs().max().item(), err
