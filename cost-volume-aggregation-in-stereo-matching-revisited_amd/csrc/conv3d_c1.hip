@@ -95,7 +95,8 @@ __global__ __launch_bounds__(256) void c1_bwd_data_kernel(C1Args a) {
     for (int r9 = 0; r9 < 9; ++r9) {
       const float4 wv = *(const float4*)(w_lds + (c * 9 + r9) * 4);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] += wv.x * g[r9][j] + wv.y * g[r9][j + 1] + wv.z * g[r9][j + 2];
+      for (int j = 0; j < 4; ++j)      // three chained FMAs (the sum-then-add form costs a multiply and an add more per tap row)
+        acc[j] = fmaf(wv.z, g[r9][j + 2], fmaf(wv.y, g[r9][j + 1], fmaf(wv.x, g[r9][j], acc[j])));
     }
     if (ok) {
       float* o = a.out + ((((long)n * a.C + c) * a.D + d) * a.H + h) * a.W + w;

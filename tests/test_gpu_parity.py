@@ -68,7 +68,7 @@ def cpu_leaf(t):
 
 # ------------------------------------------------------------------------------------- volumes
 @pytest.mark.parametrize("shape", [(2, 32, 4, 5, 18, 6), (1, 320, 40, 3, 10, 12), (1, 320, 40, 6, 64, 16),
-                                   (2, 64, 8, 7, 40, 48)])
+                                   (2, 64, 8, 7, 40, 48), (1, 80, 10, 2, 240, 48), (1, 32, 8, 3, 256, 20)])
 def test_gwc_volume(shape):
     _, ops = _mods()
     B, C, G, H, W, D = shape
