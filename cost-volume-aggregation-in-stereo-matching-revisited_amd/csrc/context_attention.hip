@@ -137,6 +137,53 @@ __global__ void ctx_bwd_preds_kernel(const float* __restrict__ preds, const int*
   }
 }
 
+// Staging of NT tensors' (8 channels x n bins x PW pixels) head tiles into LDS: hardware-predicated 16-byte buffer loads, six per
+// tensor and thread in flight at once (HW % 4 == 0), instead of a loop of conditional 4-byte loads that waits for memory once
+// per iteration -- with ONE workgroup per CU (the backward kernel's 107 KB of LDS) that loop was 24 round trips = most of the
+// kernel (attn_bwd 800 us per launch, tools/attn_time.py).  scale multiplies tensor `sidx` (the pre-scaled q tile).
+template <int NT, int PW>
+__device__ __forceinline__ void attn_stage(const float* const (&src)[NT], float* const (&dst)[NT], long hb, int n, long HW,
+                                           long pix0, int tid, int sidx, float scale) {
+  constexpr int NTH = 8 * PW, PQ = PW / 4, RQ = 6;
+  const int nq = 2 * n * PW;                       // quads per tensor
+  if ((HW & 3) == 0 && 8L * n * HW * 4 < 0x7ffffff0L) {
+    __amdgpu_buffer_rsrc_t r[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) r[t] = dca_rsrc(src[t] + hb, 8L * n * HW * 4);
+    for (int i0 = 0; i0 < nq; i0 += NTH * RQ) {
+      float4 v[NT][RQ];
+#pragma unroll
+      for (int k = 0; k < RQ; ++k) {
+        const int it = i0 + tid + NTH * k, p4 = it & (PQ - 1), cj = it / PQ;
+        const int ok = (int)(it < nq) & (int)(pix0 + 4 * p4 < HW);
+        const int off = (int)(((long)cj * HW + pix0 + 4 * p4) * 4);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) v[t][k] = dca_bload4(r[t], off, ok);
+      }
+#pragma unroll
+      for (int k = 0; k < RQ; ++k) {
+        const int it = i0 + tid + NTH * k;
+        if (it < nq) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            float4 w = v[t][k];
+            if (t == sidx) { w.x *= scale; w.y *= scale; w.z *= scale; w.w *= scale; }
+            *(float4*)(dst[t] + 4 * it) = w;
+          }
+        }
+      }
+    }
+  } else {
+    for (int it = tid; it < 8 * n * PW; it += NTH) {
+      const int p = it & (PW - 1), cj = it / PW;
+      const bool ok = pix0 + p < HW;
+      const long g = hb + (long)cj * HW + pix0 + p;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) dst[t][it] = ok ? src[t][g] * (t == sidx ? scale : 1.f) : 0.f;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // disparity attention, forward.  grid (ceil(HW/PW), heads, B); thread = (pixel lane 0..PW-1, query group 0..7);
 // a thread owns the queries qg + 8t, t < QPT = ceil(n/8) <= 8, i.e. n <= 64 disparity bins.  PW = 32 pixels per
@@ -153,11 +200,10 @@ __global__ __launch_bounds__(8 * PW) void attn_fwd_kernel(const float* __restric
   const int head = blockIdx.y, b = blockIdx.z;
   const long pix0 = (long)blockIdx.x * PW, pix = pix0 + pl;
   const long hb = ((long)b * C + head * 8) * n * HW;  // offset of (b, head*8, 0, 0)
-  for (int it = tid; it < 8 * n * PW; it += 8 * PW) {
-    const int p = it & (PW - 1), cj = it / PW;  // cj = c*n + j
-    const bool ok = pix0 + p < HW;
-    ks[it] = ok ? k[hb + (long)cj * HW + pix0 + p] : 0.f;
-    vs[it] = ok ? v[hb + (long)cj * HW + pix0 + p] : 0.f;
+  {
+    const float* const src[2] = {k, v};
+    float* const dst[2] = {ks, vs};
+    attn_stage<2, PW>(src, dst, hb, n, HW, pix0, tid, -1, 1.f);
   }
   __syncthreads();
   if (pix >= HW) return;
@@ -173,6 +219,7 @@ __global__ __launch_bounds__(8 * PW) void attn_fwd_kernel(const float* __restric
       ctx[t][c] = 0.f;
     }
   }
+#pragma unroll 4
   for (int j = 0; j < n; ++j) {
     float kj[8], vj[8];
 #pragma unroll
@@ -226,14 +273,10 @@ __global__ __launch_bounds__(8 * PW) void attn_bwd_kernel(const float* __restric
   const long pix0 = (long)blockIdx.x * PW, pix = pix0 + pl;
   const long hb = ((long)b * C + head * 8) * n * HW;
   const float scale = 0.35355339059327373f;
-  for (int it = tid; it < tile; it += 8 * PW) {
-    const int p = it & (PW - 1), cj = it / PW;
-    const bool ok = pix0 + p < HW;
-    const long g = hb + (long)cj * HW + pix0 + p;
-    ks[it] = ok ? k[g] : 0.f;
-    vs[it] = ok ? v[g] : 0.f;
-    qs[it] = ok ? q[g] * scale : 0.f;
-    gs[it] = ok ? dout[g] : 0.f;
+  {
+    const float* const src[4] = {k, v, q, dout};
+    float* const dst[4] = {ks, vs, qs, gs};
+    attn_stage<4, PW>(src, dst, hb, n, HW, pix0, tid, 2, scale);
   }
   __syncthreads();
   {
@@ -249,6 +292,7 @@ __global__ __launch_bounds__(8 * PW) void attn_bwd_kernel(const float* __restric
       }
       m[t] = -INFINITY; l[t] = 0.f; dnum[t] = 0.f;
     }
+#pragma unroll 4
     for (int j = 0; j < n; ++j) {
       float kj[8], vj[8];
 #pragma unroll
@@ -283,6 +327,7 @@ __global__ __launch_bounds__(8 * PW) void attn_bwd_kernel(const float* __restric
         st[(2 * n + i) * PW + pl] = Dsum[t];
       }
     }
+#pragma unroll 4
     for (int j = 0; j < n; ++j) {
       float kj[8], vj[8];
 #pragma unroll
@@ -326,6 +371,7 @@ __global__ __launch_bounds__(8 * PW) void attn_bwd_kernel(const float* __restric
         dvj[t][c] = 0.f;
       }
     }
+#pragma unroll 4
     for (int i = 0; i < n; ++i) {
       float qv[8], go[8];
 #pragma unroll
