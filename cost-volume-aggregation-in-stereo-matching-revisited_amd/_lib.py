@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(HERE, "libdca_hip.so")
 
 _p, _i, _l, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double
 
-ABI_VERSION = 16  # == DCA_ABI_VERSION of include/dca_hip.h
+ABI_VERSION = 17  # == DCA_ABI_VERSION of include/dca_hip.h
 
 # name -> (restype, argtypes); mirrors include/dca_hip.h one to one
 SIGNATURES = {
@@ -70,7 +70,7 @@ SIGNATURES = {
     "dca_bn_apply": (_i, [_p, _p, _p, _p, _p, _i, _i, _l, _f, _p, _p, _p]),
     "dca_bn_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _l, _f, _i, _p, _p]),
     "dca_avgpool3d_fwd": (_i, [_p, _p, _l, _i, _i, _i, _p]),
-    "dca_avgpool3d_bwd": (_i, [_p, _p, _p, _l, _i, _i, _i, _p]),
+    "dca_avgpool3d_bwd": (_i, [_p, _p, _p, _p, _l, _i, _i, _i, _p]),
     "dca_trilinear_fwd": (_i, [_p, _p, _l, _i, _i, _i, _i, _p]),
     "dca_trilinear_bwd": (_i, [_p, _p, _l, _i, _i, _i, _i, _p]),
     "dca_context_inject_fwd": (_i, [_p] * 8 + [_i, _i, _i, _l, _p]),

@@ -593,8 +593,8 @@ __global__ __launch_bounds__(256) void avgpool3d_fwd_kernel(const float* __restr
 }
 
 __global__ __launch_bounds__(256) void avgpool3d_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
-                                                            const float* __restrict__ res, int Di, int Hi, int Wi, int Do,
-                                                            int Ho, int Wo) {
+                                                            const float* __restrict__ res, const float* __restrict__ res2,
+                                                            int Di, int Hi, int Wi, int Do, int Ho, int Wo) {
   const long row = blockIdx.x;
   const int d = (int)(row % Di);
   const long nc = row / Di;
@@ -617,7 +617,9 @@ __global__ __launch_bounds__(256) void avgpool3d_bwd_kernel(const float* __restr
           const int ok = (a <= dn) & (b <= hn) & (c <= wn) & (int)(od < Do) & (int)(oh < Ho) & (int)(ow < Wo);
           s += dca_bload1(gr, ((od * Ho + oh) * Wo + ow) * 4, ok);
         }
-    gx[row * HW + i] = s * (1.0f / 27.0f) + (res ? res[row * HW + i] : 0.f);
+    float o = s * (1.0f / 27.0f) + (res ? res[row * HW + i] : 0.f);
+    if (res2) o += res2[row * HW + i];
+    gx[row * HW + i] = o;
   }
 }
 
@@ -682,8 +684,8 @@ __global__ __launch_bounds__(256) void avgpool3d_fwd_tiled_kernel(const float* _
 // was bound by its load instructions, 478 us per batch-4 launch against a 330 us stream); per-element summation order as in
 // the scalar kernel (bitwise identical results).
 __global__ __launch_bounds__(256) void avgpool3d_bwd_vec_kernel(const float* __restrict__ gy, float* __restrict__ gx,
-                                                                const float* __restrict__ res, int Di, int Hi, int Wi, int Do,
-                                                                int Ho, int Wo) {
+                                                                const float* __restrict__ res, const float* __restrict__ res2,
+                                                                int Di, int Hi, int Wi, int Do, int Ho, int Wo) {
   const int BD = Di / 2 + 1, BH = Hi / 2 + 1;
   const int bd = (int)(blockIdx.x % BD);
   const long nc = blockIdx.x / BD;
@@ -725,8 +727,12 @@ __global__ __launch_bounds__(256) void avgpool3d_bwd_vec_kernel(const float* __r
           o[e] = s * (1.0f / 27.0f);
         }
         const long off = ((nc * Di + d) * Hi + h) * (long)Wi + 4 * t;
-        if (res) {   // + another gradient of the same input (ops._PoolFork): saves autograd's separate accumulation pass
+        if (res) {   // + other gradients of the same input (ops._PoolFork): saves autograd's separate accumulation passes
           const float4 r = *(const float4*)(res + off);
+          o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+        }
+        if (res2) {
+          const float4 r = *(const float4*)(res2 + off);
           o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
         }
         *(float4*)(gx + off) = make_float4(o[0], o[1], o[2], o[3]);
@@ -1122,18 +1128,18 @@ extern "C" int dca_avgpool3d_fwd(const float* x, float* y, long NC, int Di, int 
   return dca_launch_status();
 }
 
-extern "C" int dca_avgpool3d_bwd(const float* gy, float* gx, const float* res, long NC, int Di, int Hi, int Wi,
-                                 hipStream_t stream) {
-  DCA_REQUIRE(gy && gx && NC > 0 && Di > 0 && Hi > 0 && Wi > 0);
+extern "C" int dca_avgpool3d_bwd(const float* gy, float* gx, const float* res, const float* res2, long NC, int Di, int Hi,
+                                 int Wi, hipStream_t stream) {
+  DCA_REQUIRE(gy && gx && NC > 0 && Di > 0 && Hi > 0 && Wi > 0 && (res || !res2));
   const int Do = (Di + 1) / 2, Ho = (Hi + 1) / 2, Wo = (Wi + 1) / 2;
   DCA_REQUIRE((long)Di * Hi * Wi * 4 < 0x7ffffff0L && NC * Di < 0x7fffffffL);
-  if (Wi % 4 == 0 && ((((uintptr_t)gx) | ((uintptr_t)res)) & 15) == 0) {
+  if (Wi % 4 == 0 && ((((uintptr_t)gx) | ((uintptr_t)res) | ((uintptr_t)res2)) & 15) == 0) {
     hipLaunchKernelGGL(avgpool3d_bwd_vec_kernel, dim3((unsigned)(NC * (Di / 2 + 1)), cdiv((long)(Hi / 2 + 1) * (Wi / 4), 1024)),
-                       dim3(256), 0, stream, gy, gx, res, Di, Hi, Wi, Do, Ho, Wo);
+                       dim3(256), 0, stream, gy, gx, res, res2, Di, Hi, Wi, Do, Ho, Wo);
     return dca_launch_status();
   }
   hipLaunchKernelGGL(avgpool3d_bwd_kernel, dim3((unsigned)(NC * Di), cdiv((long)Hi * Wi, 1024)), dim3(256), 0, stream, gy,
-                     gx, res, Di, Hi, Wi, Do, Ho, Wo);
+                     gx, res, res2, Di, Hi, Wi, Do, Ho, Wo);
   return dca_launch_status();
 }
 

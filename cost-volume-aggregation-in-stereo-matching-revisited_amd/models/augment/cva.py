@@ -116,7 +116,10 @@ class cva(nn.Module):
         if downsample:
             # pooled input + the input itself for `fuse` from one autograd node (ops._PoolFork): the two gradients of the
             # cost volume are summed inside the pooling backward kernel
-            pooled, cost_volume = ops.avg_pool3d_fork(cost_volume)
+            if res_post is cost_volume:      # `cost0 + augmented_cost`: a third reader of the same tensor
+                pooled, cost_volume, res_post = ops.avg_pool3d_fork(cost_volume, third=True)
+            else:
+                pooled, cost_volume = ops.avg_pool3d_fork(cost_volume)
             cost_down = self.downsample[1](pooled, slope=0.0)
             prob_volume = self.classify(cost_down).squeeze(1)
             aug_down = self.slc_net(cost_down, prob_volume)

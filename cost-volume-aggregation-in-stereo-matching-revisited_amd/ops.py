@@ -1338,7 +1338,7 @@ class _AvgPool3d(torch.autograd.Function):
         N, C, D, H, W = ctx.shape
         gx = torch.empty(ctx.shape, device=gy.device, dtype=torch.float32)
         with torch.cuda.device_of(gy):
-            _chk(_L().dca_avgpool3d_bwd(_ptr(gy), _ptr(gx), None, N * C, D, H, W, _stream()), "dca_avgpool3d_bwd")
+            _chk(_L().dca_avgpool3d_bwd(_ptr(gy), _ptr(gx), None, None, N * C, D, H, W, _stream()), "dca_avgpool3d_bwd")
         return gx
 
 
@@ -1348,34 +1348,43 @@ class _PoolFork(torch.autograd.Function):
     gradient inside the pooling backward kernel (`res`) instead of leaving the sum to autograd's accumulation pass."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, third):
         x = _req(x, "avg_pool3d")
         N, C, D, H, W = x.shape
         y = torch.empty((N, C, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2), device=x.device, dtype=torch.float32)
         with torch.cuda.device_of(x):
             _chk(_L().dca_avgpool3d_fwd(_ptr(x), _ptr(y), N * C, D, H, W, _stream()), "dca_avgpool3d_fwd")
         ctx.shape = tuple(x.shape)
+        ctx.set_materialize_grads(False)
+        if third:       # a third consumer of x (the block's `cost0 + augmented_cost`): its gradient joins inside the same kernel
+            return y, x.view_as(x), x.view_as(x)
         return y, x.view_as(x)
 
     @staticmethod
-    def backward(ctx, gy, gx2):
+    def backward(ctx, gy, gx2, gx3=None):
+        extra = [g for g in (gx2, gx3) if g is not None]
         if gy is None:
-            return gx2
+            return (extra[0] + extra[1] if len(extra) == 2 else (extra[0] if extra else None)), None
         gy = _req(gy, "avg_pool3d.backward")
-        res = _opt(gx2, "avg_pool3d.backward")
+        res = _opt(extra[0], "avg_pool3d.backward") if extra else None
+        res2 = _opt(extra[1], "avg_pool3d.backward") if len(extra) == 2 else None
         N, C, D, H, W = ctx.shape
         gx = torch.empty(ctx.shape, device=gy.device, dtype=torch.float32)
         with torch.cuda.device_of(gy):
-            _chk(_L().dca_avgpool3d_bwd(_ptr(gy), _ptr(gx), _ptr(res), N * C, D, H, W, _stream()), "dca_avgpool3d_bwd")
-        return gx
+            _chk(_L().dca_avgpool3d_bwd(_ptr(gy), _ptr(gx), _ptr(res), _ptr(res2), N * C, D, H, W, _stream()),
+                 "dca_avgpool3d_bwd")
+        return gx, None
 
 
-def avg_pool3d_fork(x):
-    """(avg_pool3d_k3s2p1(x), x') with x' = x for a second consumer whose gradient is added inside the pooling backward
-    kernel (training path; plain pooling and x itself otherwise)"""
+def avg_pool3d_fork(x, third=False):
+    """(avg_pool3d_k3s2p1(x), x'[, x'']) with x' = x'' = x for further consumers whose gradients are added inside the pooling
+    backward kernel (training path; plain pooling and x itself otherwise)"""
     if PAIR_FUSE and torch.is_grad_enabled() and x.requires_grad and x.dtype == torch.float32:
-        return _PoolFork.apply(x)
-    return avg_pool3d_k3s2p1(x), x
+        outs = _PoolFork.apply(x, bool(third))
+        for o in outs[1:]:
+            _copy_tags(x, o)        # the aliases are x: its per-channel maxima / packed twin stay valid (residual bounds)
+        return outs
+    return (avg_pool3d_k3s2p1(x), x, x) if third else (avg_pool3d_k3s2p1(x), x)
 
 
 class _Trilinear(torch.autograd.Function):

@@ -23,7 +23,7 @@ extern "C" {
 
 /* Bumped whenever an argument list below changes; the ctypes loader (_lib.py) refuses a library built from another
  * version of this header. */
-#define DCA_ABI_VERSION 16
+#define DCA_ABI_VERSION 17
 int dca_abi_version(void);
 
 /* storage types of the reduced-precision inference path (0 = fp32) */
@@ -309,7 +309,8 @@ int dca_bn_backward_pack(const float* dz, const float* y, const float* stats, do
 /* ---- AvgPool3d((3,3,3), stride 2, padding 1) -- models/augment/cva.py:39 ---------------------------- */
 int dca_avgpool3d_fwd(const float* x, float* y, long NC, int Di, int Hi, int Wi, hipStream_t stream);
 /* res (may be null): another gradient of the pooled tensor's input, added to gx on the way (ops._PoolFork) */
-int dca_avgpool3d_bwd(const float* gy, float* gx, const float* res, long NC, int Di, int Hi, int Wi, hipStream_t stream);
+int dca_avgpool3d_bwd(const float* gy, float* gx, const float* res, const float* res2, long NC, int Di, int Hi, int Wi,
+                     hipStream_t stream);   /* res / res2 (may be null): further gradients of the same input, added on the way */
 
 /* ---- F.interpolate(scale_factor=(s,s,s), mode='trilinear'), align_corners=False -----------------------
  * models/augment/cva.py:64 (s = 2), models/gwcnet_dca_g.py:251,256 (s = 2), :261 (s = 8). */

@@ -5,7 +5,7 @@ from dcanet_amd import ops
 dev = torch.device("cuda")
 lib = ops._L()
 gy = torch.randn(4, 32, 24, 68, 120, device=dev); res = torch.randn(4, 32, 48, 136, 240, device=dev); gx = torch.empty_like(res)
-f = lambda: ops._chk(lib.dca_avgpool3d_bwd(ops._ptr(gy), ops._ptr(gx), ops._ptr(res), 128, 48, 136, 240, ops._stream()), "pool bwd")
+f = lambda: ops._chk(lib.dca_avgpool3d_bwd(ops._ptr(gy), ops._ptr(gx), ops._ptr(res), None, 128, 48, 136, 240, ops._stream()), "pool bwd")
 for _ in range(3): f()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
