@@ -139,15 +139,26 @@ __global__ void up_softargmin_bwd2_kernel(const float* __restrict__ g1, float* _
     const int yc = t % hc;
     const long bk = t / hc;
     const float* p = g1 + bk * (long)H * W;
-    const int y0 = max(0, S * yc - (S + 1) / 2), y1 = min(H - 1, S * yc + (3 * S) / 2 - 1 + (S & 1));
-    const int x0 = max(0, S * xc - (S + 1) / 2), x1 = min(W - 1, S * xc + (3 * S) / 2 - 1 + (S & 1));
+    // the footprint of a coarse sample is at most 2S fine positions per axis; the S-dependent weights are evaluated once per
+    // axis (2 x 2S lin_w calls) instead of once per footprint element ((2S)^2 + 2S calls: the kernel was bound by them)
+    const int yb = S * yc - (S + 1) / 2, xb = S * xc - (S + 1) / 2;
+    float wy[2 * S], wx[2 * S];
+#pragma unroll
+    for (int j = 0; j < 2 * S; ++j) {
+      const int y = yb + j, x = xb + j;
+      wy[j] = ((unsigned)y < (unsigned)H) ? lin_w(y, yc, rs, hc) : 0.f;
+      wx[j] = ((unsigned)x < (unsigned)W) ? lin_w(x, xc, rs, wc) : 0.f;
+    }
     float acc = 0.f;
-    for (int y = y0; y <= y1; ++y) {
-      const float wh = lin_w(y, yc, rs, hc);
-      if (wh == 0.f) continue;
+#pragma unroll
+    for (int jy = 0; jy < 2 * S; ++jy) {
+      if (wy[jy] == 0.f) continue;
+      const float* row = p + (long)(yb + jy) * W + xb;
       float r = 0.f;
-      for (int x = x0; x <= x1; ++x) r += lin_w(x, xc, rs, wc) * p[(long)y * W + x];
-      acc += wh * r;
+#pragma unroll
+      for (int jx = 0; jx < 2 * S; ++jx)
+        if (wx[jx] != 0.f) r += wx[jx] * row[jx];
+      acc += wy[jy] * r;
     }
     glogits[idx] = acc;
   }
