@@ -28,10 +28,10 @@ template <typename MT> __device__ __forceinline__ unsigned g_pack2(float a, floa
 template <typename MT>
 __global__ __launch_bounds__(256) void avgpool3d_lp_kernel(const unsigned short* __restrict__ x, float* __restrict__ y,
                                                            int Di, int Hi, int Wi, int Do, int Ho, int Wo) {
-  const int p = blockIdx.x * 256 + threadIdx.x, oh = blockIdx.y;
+  const int p = blockIdx.x * 64 + (threadIdx.x & 63), oh = blockIdx.y * 4 + (threadIdx.x >> 6);   // a wave = 64 pairs of one row
   const int od = blockIdx.z % Do;
   const long nc = blockIdx.z / Do;
-  if (2 * p >= Wo) return;
+  if (2 * p >= Wo || oh >= Ho) return;
   const long plane = (long)Di * Hi * Wi;
   const __amdgpu_buffer_rsrc_t xr = dca_rsrc(x + nc * plane, plane * 2);
   float s0 = 0.f, s1 = 0.f;
@@ -58,10 +58,10 @@ __global__ __launch_bounds__(256) void avgpool3d_lp_kernel(const unsigned short*
 template <typename MT>
 __global__ __launch_bounds__(256) void trilinear_up2_lp_kernel(const float* __restrict__ x, unsigned* __restrict__ y,
                                                                int Di, int Hi, int Wi) {
-  const int mw = blockIdx.x * 256 + threadIdx.x, mh = blockIdx.y;
+  const int mw = blockIdx.x * 64 + (threadIdx.x & 63), mh = blockIdx.y * 4 + (threadIdx.x >> 6);   // a wave = 64 w of one row
   const int md = blockIdx.z % Di;
   const long nc = blockIdx.z / Di;
-  if (mw >= Wi) return;
+  if (mw >= Wi || mh >= Hi) return;
   const float* p = x + nc * Di * Hi * Wi;
   const int dm = max(md - 1, 0), dp = min(md + 1, Di - 1), hm = max(mh - 1, 0), hp = min(mh + 1, Hi - 1);
   const int wm = max(mw - 1, 0), wp = min(mw + 1, Wi - 1);
@@ -98,7 +98,7 @@ extern "C" int dca_avgpool3d_lp_fwd(const void* x, float* y, long NC, int Di, in
   DCA_REQUIRE(Wi % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 7) == 0);
   const int Do = (Di + 1) / 2, Ho = (Hi + 1) / 2, Wo = (Wi + 1) / 2;
   DCA_REQUIRE(Ho <= 65535 && NC * Do <= 65535 && (long)Di * Hi * Wi * 2 < 0x7ffffff0L);
-  const dim3 grid(cdiv(Wo / 2, 256), Ho, (unsigned)(NC * Do));
+  const dim3 grid(cdiv(Wo / 2, 64), cdiv(Ho, 4), (unsigned)(NC * Do));
   if (dtype == DCA_BF16)
     hipLaunchKernelGGL(avgpool3d_lp_kernel<__bf16>, grid, dim3(256), 0, stream, (const unsigned short*)x, y, Di, Hi, Wi,
                        Do, Ho, Wo);
@@ -112,7 +112,7 @@ extern "C" int dca_trilinear_up2_lp_fwd(const float* x, void* y, long NC, int Di
                                         hipStream_t stream) {
   DCA_REQUIRE(x && y && NC > 0 && Di > 0 && Hi > 0 && Wi > 0 && (dtype == DCA_BF16 || dtype == DCA_FP16));
   DCA_REQUIRE(Hi <= 65535 && NC * Di <= 65535 && (((uintptr_t)y) & 3) == 0);
-  const dim3 grid(cdiv(Wi, 256), Hi, (unsigned)(NC * Di));
+  const dim3 grid(cdiv(Wi, 64), cdiv(Hi, 4), (unsigned)(NC * Di));
   if (dtype == DCA_BF16)
     hipLaunchKernelGGL(trilinear_up2_lp_kernel<__bf16>, grid, dim3(256), 0, stream, x, (unsigned*)y, Di, Hi, Wi);
   else

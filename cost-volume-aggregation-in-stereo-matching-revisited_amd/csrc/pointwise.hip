@@ -824,13 +824,16 @@ __global__ void trilinear_bwd_kernel(const float* __restrict__ gy, float* __rest
 
 // x2 up-sampling, specialised: per dim o=2m -> 0.25 x[m-1] + 0.75 x[m] (m=0: x[0]); o=2m+1 -> 0.75 x[m] + 0.25 x[m+1]
 // (m=n-1: x[n-1]).  One thread per coarse cell writes its 2x2x2 outputs (two float2 stores per row pair); grid
-// (W tiles, H, NC*D) so no 64-bit div/mod chains.
+// (W tiles of 64, H tiles of 4, NC*D) so no 64-bit div/mod chains; a wave is 64 consecutive w of one row (a 256-wide block
+// per row left 136 of 256 lanes idle at W = 120: 276 -> 259 us per batch-4 launch).  Measured and withdrawn in round 3: two
+// cells per thread with 16-byte stores (308 us: 36 gather loads per thread), the left / right samples from the neighbouring
+// lanes instead of loads (355 us: 18 ds_bpermute + divergent edge loads).
 __global__ __launch_bounds__(256) void trilinear_up2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                 int Di, int Hi, int Wi) {
-  const int mw = blockIdx.x * 256 + threadIdx.x, mh = blockIdx.y;
+  const int mw = blockIdx.x * 64 + (threadIdx.x & 63), mh = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int md = blockIdx.z % Di;
   const long nc = blockIdx.z / Di;
-  if (mw >= Wi) return;
+  if (mw >= Wi || mh >= Hi) return;
   const float* p = x + nc * Di * Hi * Wi;
   const int dm = max(md - 1, 0), dp = min(md + 1, Di - 1), hm = max(mh - 1, 0), hp = min(mh + 1, Hi - 1);
   const int wm = max(mw - 1, 0), wp = min(mw + 1, Wi - 1);
@@ -1147,8 +1150,8 @@ extern "C" int dca_trilinear_fwd(const float* x, float* y, long NC, int Di, int 
                                  hipStream_t stream) {
   DCA_REQUIRE(x && y && NC > 0 && Di > 0 && Hi > 0 && Wi > 0 && scale >= 1);
   if (scale == 2 && Hi <= 65535 && NC * Di <= 65535 && (((uintptr_t)y & 7) == 0)) {
-    hipLaunchKernelGGL(trilinear_up2_fwd_kernel, dim3(cdiv(Wi, 256), Hi, (unsigned)(NC * Di)), dim3(256), 0, stream, x, y,
-                       Di, Hi, Wi);
+    hipLaunchKernelGGL(trilinear_up2_fwd_kernel, dim3(cdiv(Wi, 64), cdiv(Hi, 4), (unsigned)(NC * Di)), dim3(256), 0, stream,
+                       x, y, Di, Hi, Wi);
     return dca_launch_status();
   }
   const long total = NC * Di * Hi * Wi * scale * scale * scale;
