@@ -49,7 +49,10 @@ constexpr int X_TERM = NHROW * XV * VB;               // 27648: [hrow][voxel][32
 constexpr int Y_TERM = NROW * TW * VB;                // 8192:  [row][voxel][32 co]
 constexpr int X_OFF = 0, Y_OFF = NT * X_TERM;
 constexpr int IMG_BYTES = Y_OFF + NT * Y_TERM;        // 71680
-constexpr int LDS_BYTES = IMG_BYTES > 4 * 7 * 4096 ? IMG_BYTES : 4 * 7 * 4096;   // the end-of-kernel reduction reuses the LDS (114688)
+// both operands packed: TWO image sets, filled by LDS-DMA (buffer_load ... lds) while the other one is multiplied: 143360;
+// otherwise one set (71680); the end-of-kernel reduction reuses the LDS (114688)
+constexpr int LDS_BYTES = 2 * IMG_BYTES;
+static_assert(LDS_BYTES >= 4 * 7 * 4096 && LDS_BYTES + 128 <= 160 * 1024, "LDS");
 constexpr int NXW = NT * NHROW * XV * 4, KXW = (NXW + 511) / 512;     // packed x: 3456 words -> 7 per thread
 constexpr int NYW = NT * NROW * TW * 4, KYW = NYW / 512;              // packed dy: 1024 words -> 2 per thread
 constexpr int NXQ = NHROW * 4 * 4, NXE = NHROW * 2 * 4, NYQ = NROW * 4 * 4;   // fp32: 384 x quads, 192 x edge voxels, 128 dy quads
@@ -210,6 +213,64 @@ __global__ __launch_bounds__(512) void wgrad3_f16x2_kernel(WX2Args a) {
       }
     }
   };
+  // Both operands packed: a tile's words go global -> LDS directly (word it of an image = LDS byte 16 it = wave-uniform base +
+  // 16 * lane: exactly what buffer_load ... lds writes; the per-lane SOURCE address carries the halo geometry, an out-of-range
+  // offset writes zeros) into the image set that is not being multiplied: no staging registers, no store phase between two
+  // barriers -- ONE barrier per tile.  (With register staging a second image set spilled: DESIGN.md section 5.)
+  // The copies are issued through inline asm: hipcc counts a builtin LDS-DMA as a pending LDS write and put `s_waitcnt
+  // vmcnt(0)` in front of the next K-step's transposing reads (it cannot see that they touch the other image set), which
+  // exposed the DMA latency twice per tile.  An asm load is outside its bookkeeping (cdna_hip_programming.md, "What hipcc does
+  // not do"), so the kernel waits itself: vmcnt(0) in front of the tile's barrier; this variant has no other vector-memory
+  // load in flight inside the tile loop.
+  typedef __attribute__((address_space(3))) char lds_char;
+  const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar copy for the LDS bases only (see the note on wq above)
+  const unsigned lds0 = (unsigned)(unsigned long)(lds_char*)smem;
+  auto desc = [&](const void* base, long bytes) __attribute__((always_inline)) {     // the words dca_rsrc builds, as SGPRs for the asm
+    const unsigned long long b = (unsigned long long)base;
+    u32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((unsigned)b);
+    r.y = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32)) & 0xffffu;
+    r.z = __builtin_amdgcn_readfirstlane((unsigned)bytes);
+    r.w = 0x00020000u;
+    return r;
+  };
+  auto glds16 = [&](u32x4 rs, int voff, unsigned lds_byte) __attribute__((always_inline)) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_byte), "s"(rs) : "memory");
+  };
+  auto glds_tile = [&](int n, int d0, int h0, int w0, int part, int buf) __attribute__((always_inline)) {
+    if constexpr (XP && YP) {
+      const u32x4 xr = desc(a.x + (long)n * xsample, xsample * 4), yr = desc(a.dy + (long)n * ysample, ysample * 4);
+      const unsigned img = lds0 + buf * IMG_BYTES;
+#pragma unroll
+      for (int k = 0; k < KXW; ++k) {
+        if ((part == 0 && k >= 4) || (part == 1 && k < 4)) continue;
+        if (512 * k + 64 * wvu < NXW) {        // NXW is a multiple of 64: whole waves
+          int crd = xcrd[k];
+          asm volatile("" : "+v"(crd));
+          const int d = d0 - 1 + (crd & 15), h = h0 - 1 + ((crd >> 4) & 15), w = w0 - 1 + ((crd >> 8) & 255);
+          const int term = (crd >> 16) & 1, g = (cx0 >> 3) + ((crd >> 20) & 3);
+          const int ok = (int)(g * 8 < a.Cx) & (int)((unsigned)d < (unsigned)a.D) & (int)((unsigned)h < (unsigned)a.H) &
+                         (int)((unsigned)w < (unsigned)a.W);
+          glds16(xr, dca_pred_off(term * (a.Cx * cstride * 2) + (g * cstride + (d * a.H + h) * a.W + w) * 16, ok),
+                 img + X_OFF + (512 * k + 64 * wvu) * 16);
+        }
+      }
+      if (part == 0) return;
+#pragma unroll
+      for (int k = 0; k < KYW; ++k) {
+        int crd = ycrd[k];
+        asm volatile("" : "+v"(crd));
+        const int d = d0 + (crd & 15), h = h0 + ((crd >> 4) & 15), w = w0 + ((crd >> 8) & 255);
+        const int term = (crd >> 16) & 1, g = (cy0 >> 3) + ((crd >> 20) & 3);
+        const int ok = (int)(g * 8 < a.Cy) & (int)(d < a.D) & (int)(h < a.H) & (int)(w < a.W);
+        glds16(yr, dca_pred_off(term * (a.Cy * cstride * 2) + (g * cstride + (d * a.H + h) * a.W + w) * 16, ok),
+               img + Y_OFF + (512 * k + 64 * wvu) * 16);
+      }
+    }
+  };
+
   // the 8 channels of one voxel -> the two f16 words of its channel group
   auto split_word = [&](const float (&v)[8], char* dst, int term_stride) __attribute__((always_inline)) {
     f16x8 hv, lv;
@@ -266,7 +327,7 @@ __global__ __launch_bounds__(512) void wgrad3_f16x2_kernel(WX2Args a) {
   // compile-time offset from one per-K-step base; the next tap's fragments are requested before this tap's MFMAs.  The
   // next tile's global loads are issued BEHIND the first K-step's MFMAs (in front of the phase their address arithmetic
   // and the memory pipe's back-pressure kept all eight waves -- and the matrix pipe -- busy).
-  auto mfma_tile = [&](auto WQC, bool more, int next_tile) __attribute__((always_inline)) {
+  auto mfma_tile = [&](auto WQC, bool more, int next_tile, int buf) __attribute__((always_inline)) {
     constexpr int WQ = decltype(WQC)::value;
     constexpr int TAP0 = 7 * WQ, TAP1 = (TAP0 + 7 < 27) ? TAP0 + 7 : 27, NTAP = TAP1 - TAP0;
 #pragma unroll 1
@@ -274,11 +335,12 @@ __global__ __launch_bounds__(512) void wgrad3_f16x2_kernel(WX2Args a) {
       if ((i == 1 || i == 2) && more) {     // in two portions: one burst of up to 18 loads stalls the memory pipe -- and the MFMAs
         int nn, nd0, nh0, nw0;
         decode(next_tile, nn, nd0, nh0, nw0);
-        load_tile(nn, nd0, nh0, nw0, i - 1);
+        if constexpr (XP && YP) glds_tile(nn, nd0, nh0, nw0, i - 1, buf ^ 1);
+        else load_tile(nn, nd0, nh0, nw0, i - 1);
       }
       // K-step (d = d0 + grp, h = h0 + i): dy row grp*TH + i; x halo rows (grp + kd, i + kh)
-      const char* yb = smem + Y_OFF + ((grp * TH + i) * TW) * VB + lane_off;
-      const char* xb = smem + X_OFF + ((grp * HH + i) * XV) * VB + lane_off;
+      const char* yb = smem + buf * IMG_BYTES + Y_OFF + ((grp * TH + i) * TW) * VB + lane_off;
+      const char* xb = smem + buf * IMG_BYTES + X_OFF + ((grp * HH + i) * XV) * VB + lane_off;
       f16x8 ay[NT];
 #pragma unroll
       for (int term = 0; term < NT; ++term) ay[term] = tr_frag(yb + term * Y_TERM);
@@ -313,21 +375,32 @@ __global__ __launch_bounds__(512) void wgrad3_f16x2_kernel(WX2Args a) {
   if (t_begin < t_end) {
     int n, d0, h0, w0;
     decode(t_begin, n, d0, h0, w0);
-    load_tile(n, d0, h0, w0);
-    store_tile();
+    if constexpr (XP && YP) {
+      glds_tile(n, d0, h0, w0, -1, 0);
+      __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): the asm copies
+    } else {
+      load_tile(n, d0, h0, w0);
+      store_tile();
+    }
     __syncthreads();
+    int buf = 0;
 #pragma unroll 1
     for (int tile = t_begin; tile < t_end; tile += t_step) {
       const bool more = tile + t_step < t_end;
       switch (wq) {
-        case 0: mfma_tile(std::integral_constant<int, 0>{}, more, tile + t_step); break;
-        case 1: mfma_tile(std::integral_constant<int, 1>{}, more, tile + t_step); break;
-        case 2: mfma_tile(std::integral_constant<int, 2>{}, more, tile + t_step); break;
-        default: mfma_tile(std::integral_constant<int, 3>{}, more, tile + t_step); break;
+        case 0: mfma_tile(std::integral_constant<int, 0>{}, more, tile + t_step, buf); break;
+        case 1: mfma_tile(std::integral_constant<int, 1>{}, more, tile + t_step, buf); break;
+        case 2: mfma_tile(std::integral_constant<int, 2>{}, more, tile + t_step, buf); break;
+        default: mfma_tile(std::integral_constant<int, 3>{}, more, tile + t_step, buf); break;
       }
-      __syncthreads();  // every wave is done reading this tile
-      if (more) store_tile();
-      __syncthreads();
+      if constexpr (XP && YP) __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): this wave's copies of the next tile have landed
+      __syncthreads();  // every wave is done reading this tile [and all copies of the next one are in LDS]
+      if constexpr (XP && YP) {
+        buf ^= 1;
+      } else {
+        if (more) store_tile();
+        __syncthreads();
+      }
     }
   }
 
