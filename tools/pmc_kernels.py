@@ -2,10 +2,10 @@
 
 Collect (on the GPU box; separate --pmc passes -- FETCH_SIZE and WRITE_SIZE do not fit one pass, and gpurun refuses
 --pmc together with the trace domains):
-    tools/pmc_collect.sh          # three rocprofv3 passes over this script -> gpurun_out/pmc_r03b_{fetch,write,sq}
+    tools/pmc_collect.sh          # three rocprofv3 passes over this script -> gpurun_out/pmc_r03c_{fetch,write,sq}
 then -- in the development container, where the snapshot's commit is known (the GPU box has no .git) -- fold them into
 profiles/r03_pmc_traffic.json (the file bench.py reads), with the commit they were taken at:
-    python tools/pmc_kernels.py --summarise gpurun_out/pmc_r03b_fetch gpurun_out/pmc_r03b_write gpurun_out/pmc_r03b_sq
+    python tools/pmc_kernels.py --summarise gpurun_out/pmc_r03c_fetch gpurun_out/pmc_r03c_write gpurun_out/pmc_r03c_sq
 
 HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB: gfx950's FETCH_SIZE tallies 128-byte requests at 64 bytes
 (MI355X_MICROARCH.md, HBM section; exact for 16-byte-per-lane streams, other access widths are uncalibrated).
