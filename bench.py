@@ -551,6 +551,10 @@ def main():
             line["roofline_other"] = {n: roof[n] for n in names[1:]}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(m, args.mode, args.cpu_rows)
+            # `vs_baseline` stays null (BASELINE.md publishes no number for this metric); the ratio to the CPU oracle timed
+            # beside it is reported under its own name -- a large ratio says nothing about kernel quality, `roofline.frac` does
+            if line["cpu_baseline"].get("value"):
+                line["vs_cpu_baseline"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
