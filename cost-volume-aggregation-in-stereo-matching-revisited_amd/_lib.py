@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(HERE, "libdca_hip.so")
 
 _p, _i, _l, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double
 
-ABI_VERSION = 17  # == DCA_ABI_VERSION of include/dca_hip.h
+ABI_VERSION = 18  # == DCA_ABI_VERSION of include/dca_hip.h
 
 # name -> (restype, argtypes); mirrors include/dca_hip.h one to one
 SIGNATURES = {
@@ -17,7 +17,7 @@ SIGNATURES = {
     "dca_gwc_volume_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "dca_concat_volume_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "dca_concat_volume_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
-    "dca_cost_volume_fwd": (_i, [_p, _p, _p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "dca_cost_volume_fwd": (_i, [_p, _p, _p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "dca_softargmin_fwd": (_i, [_p, _p, _i, _i, _l, _i, _p]),
     "dca_softargmin_bwd": (_i, [_p, _p, _p, _i, _i, _l, _i, _p]),
     "dca_up_softargmin_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),

@@ -106,7 +106,7 @@ __device__ __forceinline__ float4 dca_bload4(__amdgpu_buffer_rsrc_t r, int byte_
 //      - atomicMax spread over 64 words was read WRONGLY inside hipGraph replays (root cause: DESIGN.md section 3,
 //        tools/graph_amax_repro.hip);
 //  * or a bound the producer computes before it writes (the packed "px2" operand format below).
-#define DCA_AMAX_CSLOTS 256
+#define DCA_AMAX_CSLOTS 1024
 // a value another kernel wrote shortly before, read with a device-coherent vector load instead of an s_load through the
 // scalar data cache
 __device__ __forceinline__ float dca_coherent_loadf(const float* p) {

@@ -978,7 +978,7 @@ static void chunking(long S, int C, int* nchunk, long* chunk_len) {
   // enough blocks to fill 256 CUs a few times over, chunks a multiple of 1024 floats; at most DCA_AMAX_CSLOTS chunks (a
   // chunk index is also a slot of the per-channel operand maxima)
   long want = (2048 + C - 1) / C;
-  if (want > DCA_AMAX_CSLOTS) want = DCA_AMAX_CSLOTS;
+  if (want > 256) want = 256;      // (<= DCA_AMAX_CSLOTS; every consumer reads all written slots)
   long len = (S + want - 1) / want;
   len = ((len + 1023) / 1024) * 1024;
   *chunk_len = len;

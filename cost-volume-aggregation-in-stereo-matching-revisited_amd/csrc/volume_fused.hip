@@ -29,6 +29,7 @@ struct VolArgs {
   int Cc;
   void* vol;            // (B, Gtot, D, H, W), Gtot = G + 2*Cc
   int B, C, H, W, D, G, Gtot;
+  unsigned* vmax;       // optional (fp32 volume): per-channel slots [g][b * H + y] <- max |volume| of this workgroup's row
 };
 
 template <typename OT> struct Out;
@@ -94,9 +95,10 @@ __global__ __launch_bounds__(256) void gwc_fused_kernel(VolArgs a) {
   const float inv = 1.0f / (float)CPG;
   const int DQ = D >> 2, rows = 256 / WQ > 0 ? 256 / WQ : 1;   // disparity quads handled concurrently
   const int xq = tid % WQ, iq0 = tid / WQ;
-  if (tid >= rows * WQ && WQ <= 256) return;
+  const bool idle = tid >= rows * WQ && WQ <= 256;
   OT* vbase = (OT*)a.vol + (((long)b * a.Gtot + g) * D) * HW + (long)y * W;
-  for (int xqq = xq; xqq < WQ; xqq += (WQ <= 256 ? WQ : 256)) {   // (WQ > 256: threads stride over the row)
+  float vm = 0.f;
+  for (int xqq = idle ? WQ : xq; xqq < WQ; xqq += (WQ <= 256 ? WQ : 256)) {   // (WQ > 256: threads stride over the row)
     const int x0 = 4 * xqq;
     float l[CPG][4];
 #pragma unroll
@@ -125,10 +127,12 @@ __global__ __launch_bounds__(256) void gwc_fused_kernel(VolArgs a) {
 #pragma unroll
       for (int di = 0; di < 4; ++di) {
         const float v[4] = {o[di][0] * inv, o[di][1] * inv, o[di][2] * inv, o[di][3] * inv};
+        vm = fmaxf(fmaxf(vm, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
         Out<OT>::store4(vbase + (long)(i0 + di) * HW + x0, v);
       }
     }
   }
+  if (a.vmax) dca_cmax_put(vm, a.vmax + (long)g * DCA_AMAX_CSLOTS + b * a.H + y);   // every thread of the workgroup arrives here
 }
 
 // concat part: channel c < Cc: L[c][x] for x >= i; channel Cc + c: R[c][x - i] for x >= i; zero for x < i.
@@ -195,8 +199,9 @@ int launch_all(const VolArgs& a, hipStream_t s) {
 
 extern "C" int dca_cost_volume_fwd(const float* const* refs, const float* const* tgts, const int* seg_channels, int nseg,
                                    const float* cref, const float* ctgt, int Cc, void* vol, int B, int H, int W,
-                                   int maxdisp, int num_groups, int dtype, hipStream_t stream) {
+                                   int maxdisp, int num_groups, int dtype, unsigned* vmax, hipStream_t stream) {
   DCA_REQUIRE(refs && tgts && seg_channels && nseg >= 1 && nseg <= 3 && vol);
+  DCA_REQUIRE(vmax == nullptr || (dtype == 0 && Cc == 0 && (long)B * H <= DCA_AMAX_CSLOTS));
   DCA_REQUIRE(B > 0 && H > 0 && W > 0 && maxdisp > 0 && num_groups > 0 && Cc >= 0);
   DCA_REQUIRE((Cc == 0) == (cref == nullptr) && (Cc == 0) == (ctgt == nullptr));
   DCA_REQUIRE(dtype == 0 || dtype == DCA_BF16 || dtype == DCA_FP16);
@@ -216,7 +221,7 @@ extern "C" int dca_cost_volume_fwd(const float* const* refs, const float* const*
   const int cpg = a.C / num_groups;
   for (int i = 0; i < nseg; ++i) DCA_REQUIRE(a.segC[i] % cpg == 0);   // no group straddles two segments
   DCA_REQUIRE((((uintptr_t)vol | (uintptr_t)cref | (uintptr_t)ctgt) & 15) == 0);
-  a.nseg = nseg; a.cL = cref; a.cR = ctgt; a.Cc = Cc; a.vol = vol;
+  a.nseg = nseg; a.cL = cref; a.cR = ctgt; a.Cc = Cc; a.vol = vol; a.vmax = vmax;
   a.B = B; a.H = H; a.W = W; a.D = maxdisp; a.G = num_groups; a.Gtot = num_groups + 2 * Cc;
   if (dtype == 0) return launch_all<float>(a, stream);
   if (dtype == DCA_BF16) return launch_all<__bf16>(a, stream);

@@ -140,9 +140,12 @@ class _CostVolume(torch.autograd.Function):
         tp = (ctypes.c_void_p * nseg)(*[t.data_ptr() for t in tgts])
         sc = (ctypes.c_int * nseg)(*segC)
         code = 0 if out_dtype == torch.float32 else LP_DTYPES[out_dtype]
+        # fp32 volume without concat part: the builder emits the per-channel maxima the first f16x2 convolution scales by
+        vmax = _cslots(num_groups, vol.device) if (CONV_X2 and AMAX_EMIT and code == 0 and Cc == 0 and B * H <= CSLOTS) else None
         with torch.cuda.device_of(vol):
             _chk(_L().dca_cost_volume_fwd(rp, tp, sc, nseg, _ptr(cref), _ptr(ctgt), Cc, _ptr(vol), B, H, W, maxdisp,
-                                          num_groups, code, _stream()), "dca_cost_volume_fwd")
+                                          num_groups, code, _ptr(vmax), _stream()), "dca_cost_volume_fwd")
+        _tls.last_vmax = (vmax, B * H)       # the caller tags the tensor it hands out (cost_volume below)
         ctx.save_for_backward(*refs, *tgts)
         ctx.meta = (maxdisp, num_groups, nseg, segC, Cc, (B, H, W))
         return vol
@@ -190,7 +193,12 @@ def cost_volume(ref, tgt, maxdisp, num_groups, cref=None, ctgt=None, out_dtype=t
         vol = gwc_volume(r1, t1, maxdisp, num_groups)
         return vol if cref is None else torch.cat((vol, concat_volume(cref, ctgt, maxdisp)), 1)
     extra = () if cref is None else (cref, ctgt)
-    return _CostVolume.apply(int(maxdisp), int(num_groups), out_dtype, len(refs), cref is not None, *refs, *tgts, *extra)
+    vol = _CostVolume.apply(int(maxdisp), int(num_groups), out_dtype, len(refs), cref is not None, *refs, *tgts, *extra)
+    vmax, nslots = getattr(_tls, "last_vmax", (None, 0))
+    _tls.last_vmax = (None, 0)
+    if vmax is not None:
+        _tag_cmax(vol, vmax, nslots)         # per-channel maxima from the builder: no read pass in front of dres0's first convolution
+    return vol
 
 
 def concat_volume(ref, tgt, maxdisp):
@@ -314,7 +322,7 @@ _X3_MIN_WORKGROUPS = 1
 # `version` = t._version at tagging time: an in-place change of t invalidates the tag.  Tensors without a tag get one read
 # pass (dca_cmax_f32).
 AMAX_STATS = {"tagged": 0, "computed": 0, "packed": 0}
-CSLOTS = 256                                               # DCA_AMAX_CSLOTS of include/dca_hip.h
+CSLOTS = 1024                                              # DCA_AMAX_CSLOTS of include/dca_hip.h
 AMAX_EMIT = os.environ.get("DCA_AMAX_EMIT", "1") != "0"    # 0: no producer-side maxima, every operand gets its read pass (A/B)
 PACK = os.environ.get("DCA_PACK", "1") != "0"              # 0: no packed px2 operands, fp32 tensors everywhere (A/B)
 

@@ -23,7 +23,7 @@ extern "C" {
 
 /* Bumped whenever an argument list below changes; the ctypes loader (_lib.py) refuses a library built from another
  * version of this header. */
-#define DCA_ABI_VERSION 17
+#define DCA_ABI_VERSION 18
 int dca_abi_version(void);
 
 /* storage types of the reduced-precision inference path (0 = fp32) */
@@ -53,7 +53,9 @@ int dca_concat_volume_bwd(const float* gvol, float* gref, float* gtgt, int B, in
  * segment width must be a multiple of channels / num_groups. */
 int dca_cost_volume_fwd(const float* const* refs, const float* const* tgts, const int* seg_channels, int nseg,
                         const float* cref, const float* ctgt, int Cc, void* vol, int B, int H, int W, int maxdisp,
-                        int num_groups, int dtype, hipStream_t stream);
+                        int num_groups, int dtype, unsigned* vmax, hipStream_t stream);
+/* vmax (may be null; fp32 volume without concat part, B * H <= DCA_AMAX_CSLOTS): per-channel slots [g][b * H + y] that receive
+ * max |volume| of group g for the f16x2 convolution that reads it (no separate dca_cmax_f32 pass) */
 
 /* ---- softmax over dim 1 / disparity_regression ---------------------------------------------------
  * x: (B,K,HW).  mode 0: out (B,K,HW) = F.softmax(x, dim=1)   (models/gwcnet_dca_g.py:238,248,...)
@@ -213,7 +215,7 @@ int dca_conv3d_wgrad_x3(const float* x, const float* dy, float* part, float* dw,
  *   dca_conv3d_x2_forward[_stats]: contracts of dca_conv3d_x3_forward[_stats]; y_cmax (may be null; forces the fused
  *       epilogue variant) = per-channel slots that receive max |y|, nslots = dca_conv3d_x2_stats_chunks(...).
  *   dca_conv3d_wgrad_x2 / _s2_x2: contracts of dca_conv3d_wgrad_x3 / the stride-2 form below; exps of both operands. */
-#define DCA_AMAX_CSLOTS 256
+#define DCA_AMAX_CSLOTS 1024
 int dca_cmax_f32(const float* x, int N, int C, long S, unsigned* slots, hipStream_t stream);
 int dca_cmax_exps(const unsigned* slots, int nslots, int C, int* exps, hipStream_t stream);
 long dca_conv3d_x2_weight_bytes(int Cin, int Cout);
