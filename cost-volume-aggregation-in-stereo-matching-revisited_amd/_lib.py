@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(HERE, "libdca_hip.so")
 
 _p, _i, _l, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double
 
-ABI_VERSION = 18  # == DCA_ABI_VERSION of include/dca_hip.h
+ABI_VERSION = 19  # == DCA_ABI_VERSION of include/dca_hip.h
 
 # name -> (restype, argtypes); mirrors include/dca_hip.h one to one
 SIGNATURES = {
@@ -50,7 +50,8 @@ SIGNATURES = {
     "dca_conv3d_x2_forward_stats": (_i, [_p, _i, _p, _p, _p, _p] + [_i] * 6 + [_p]),
     "dca_conv3d_s2x2_weight_bytes": (_l, [_i, _i]),
     "dca_conv3d_s2x2_prep_weight": (_i, [_p, _p, _i, _i, _i, _i, _p, _i, _p, _p]),
-    "dca_conv3d_s2x2_forward": (_i, [_p, _p, _p, _p, _p] + [_i] * 6 + [_p]),
+    "dca_conv3d_s2x2_out_slots": (_l, [_i] * 5),
+    "dca_conv3d_s2x2_forward": (_i, [_p, _p, _p, _p, _p, _p, _f, _p, _p] + [_i] * 6 + [_p]),
     "dca_conv3d_wgrad_x2_workspace": (_l, [_i] * 6),
     "dca_conv3d_wgrad_s2_x2_workspace": (_l, [_i] * 6),
     "dca_conv3d_wgrad_s2_x2": (_i, [_p] * 6 + [_i] * 6 + [_l, _l, _p]),

@@ -52,7 +52,7 @@ constexpr int NSTEP = 7;                           // K-steps of 4 taps x 4 chan
 constexpr int A_CHUNK = NSTEP * 2 * 2 * 1024;      // [step][channel block of 32][term][64 lanes x 16 B] = 28672
 constexpr int LDS_BYTES = 2 * B_BYTES + 2 * A_CHUNK;   // 155264
 constexpr int MAX_CIN = 256;
-constexpr int TAB_BYTES = (MAX_CIN + 64) * 4;      // xexps[MAX_CIN] | f_o[64]
+constexpr int TAB_BYTES = (MAX_CIN + 64 + 128 + 8 * 64) * 4;   // xexps[MAX_CIN] | f_o[64] | scale[64] shift[64] | per-wave maxima [8][64] (EPI)
 constexpr int NQ = NROW * 16;                      // 720 quad items per chunk
 constexpr int NE0 = NQ - 512;                      // threads [NE0, NE0 + NROW) carry the 45 edge items (they have one quad item)
 constexpr int NA_ITEMS = A_CHUNK / 16;             // 1792
@@ -70,6 +70,10 @@ struct S2Args {
   int nTD, nTH, nTW;
   const int* xexps;          // scale exponent of every input channel (Cin ints)
   const int* ofo;            // behind the packed weight image: f_o of every output channel (blocks of 64)
+  const float* scale;        // EPI (inference): y = act(conv * scale[c] + shift[c]) [+ res_post]; null: identity affine
+  const float* shift;
+  float slope;
+  unsigned* y_cmax;          // EPI: optional per-channel slots [c][blockIdx.x] <- max |y| (dca_common.h)
   int abl;                   // ablation switches (DCA_S2_ABL, tools/s2_time.py): 1 no staging loads, 2 no LDS stores, 4 no split
 };
 
@@ -90,12 +94,17 @@ __device__ __forceinline__ constexpr int s2_toff(int t) {
   return (kw == 1 ? B_PLANE : 0) + (kd * IH + kh) * ROWB + (kw == 1 ? 0 : 1 + kw / 2) * 8;
 }
 
+// EPI: the inference epilogue (folded BatchNorm + activation, per-channel output maxima for the f16x2 convolution that reads
+// y) -- compiled out of the training launches, whose output goes to a separate BatchNorm pass
+template <bool EPI>
 __global__ __launch_bounds__(512) void conv3s2_f16x2_kernel(S2Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* b_lds = smem;
   char* a_lds = smem + 2 * B_BYTES;
   int* xe_lds = (int*)(smem + LDS_BYTES);
   int* fo_lds = xe_lds + MAX_CIN;
+  float* aff_lds = (float*)(fo_lds + 64);         // scale[64] | shift[64]
+  float* ycm_lds = aff_lds + 128;                 // [wave][64 channels]
 
   // tid >> 6 stays a per-lane value on purpose (no readfirstlane): see conv3d_wgrad_f16x2.hip
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, half = lane >> 5;
@@ -104,9 +113,22 @@ __global__ __launch_bounds__(512) void conv3s2_f16x2_kernel(S2Args a) {
   const int nx = gridDim.x >= 8 ? 8 : 1, xcd = blockIdx.x % nx;
   const int cnt = (gridDim.x - xcd + nx - 1) / nx;
   const int t_begin = (int)(T * xcd / nx) + blockIdx.x / nx, t_end = (int)(T * (xcd + 1) / nx), t_step = cnt;
-  if (t_begin >= t_end) return;
+  if (t_begin >= t_end) {
+    if constexpr (EPI) {   // a workgroup without tiles still owns its slot of the per-channel maxima
+      if (a.y_cmax && tid < 64 && cblk * 64 + tid < a.Cout) a.y_cmax[(long)(cblk * 64 + tid) * DCA_AMAX_CSLOTS + blockIdx.x] = 0u;
+    }
+    return;
+  }
   for (int i = tid; i < a.NC4 * 4; i += 512) xe_lds[i] = i < a.Cin ? dca_coherent_loadi(a.xexps + i) : 0;
   if (tid < 64) fo_lds[tid] = dca_coherent_loadi(a.ofo + cblk * 64 + tid);
+  if constexpr (EPI) {
+    if (tid < 64) {
+      const int co = min(cblk * 64 + tid, a.Cout - 1);
+      aff_lds[tid] = a.scale ? a.scale[co] : 1.f;
+      aff_lds[64 + tid] = a.scale ? a.shift[co] : 0.f;
+    }
+    ycm_lds[tid] = 0.f;      // 8 x 64 = 512 entries
+  }
 
   const int dl = wv >> 2, hl = wv & 3;
   const int lanebase = ((2 * dl) * IH + 2 * hl) * ROWB + l31 * 8;
@@ -311,8 +333,17 @@ __global__ __launch_bounds__(512) void conv3s2_f16x2_kernel(S2Args a) {
           const int cl = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, co = cblk * 64 + cl;
           const int okc = ok & (int)(co < a.Cout);
           float v = ldexpf(acc[cb][r], -fo_lds[cl]);
+          if constexpr (EPI) v = act_apply(v * aff_lds[cl] + aff_lds[64 + cl], a.slope);
           if (has_post) v += dca_bload1(qr, vbase + co * ostride * 4, okc);
           dca_bstore1(yr, v, vbase + co * ostride * 4, okc);
+          if constexpr (EPI) {
+            if (a.y_cmax) {      // wave-half maximum of this channel -> the wave's own LDS row (one writer lane, no atomics)
+              float m = okc ? fabsf(v) : 0.f;
+#pragma unroll
+              for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+              if (l31 == 0) ycm_lds[wv * 64 + cl] = fmaxf(ycm_lds[wv * 64 + cl], m);
+            }
+          }
           acc[cb][r] = 0.f;
         }
       }
@@ -321,6 +352,15 @@ __global__ __launch_bounds__(512) void conv3s2_f16x2_kernel(S2Args a) {
     cur = st;
     st = ld;
     advance(ld);
+  }
+  if constexpr (EPI) {
+    if (a.y_cmax) {      // (the loop's last barrier has passed: every wave's row is complete)
+      if (tid < 64 && cblk * 64 + tid < a.Cout) {
+        float m = ycm_lds[tid];
+        for (int w = 1; w < 8; ++w) m = fmaxf(m, ycm_lds[w * 64 + tid]);
+        a.y_cmax[(long)(cblk * 64 + tid) * DCA_AMAX_CSLOTS + blockIdx.x] = __float_as_uint(m);
+      }
+    }
   }
 }
 
@@ -427,14 +467,35 @@ extern "C" int dca_conv3d_s2x2_prep_weight(const float* w, void* wx, int A, int 
   return dca_launch_status();
 }
 
-// y = conv3d(x, w, stride 2, padding 1) [+ res_post], fp32 tensors: x (N, Cin, Di, Hi, Wi) with Wi % 4 == 0 and 16-byte
-// aligned, y (N, Cout, (Di+1)/2, (Hi+1)/2, (Wi+1)/2); xexps / wx from dca_conv3d_s2x2_prep_weight for THIS operand.
-extern "C" int dca_conv3d_s2x2_forward(const float* x, const int* xexps, const void* wx, float* y, const float* res_post, int N,
+// slots per channel that dca_conv3d_s2x2_forward fills in y_cmax (= its workgroups per block of 64 output channels)
+extern "C" long dca_conv3d_s2x2_out_slots(int N, int Cout, int Di, int Hi, int Wi) {
+  if (N <= 0 || Cout <= 0 || Di <= 0 || Hi <= 0 || Wi <= 0) return 0;
+  const long tiles = (long)N * cdiv((Di + 1) / 2, TD) * cdiv((Hi + 1) / 2, TH) * cdiv((Wi + 1) / 2, TW);
+  int ncu = 256;
+  {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+        v > 0)
+      ncu = v;
+  }
+  const int cblks = (Cout + 63) / 64;
+  long gx = ncu / cblks > 0 ? ncu / cblks : 1;
+  return gx < tiles ? gx : tiles;
+}
+
+// y = act(conv3d(x, w, stride 2, padding 1) * scale[c] + shift[c]) + res_post (scale / shift / res_post may be null, slope 1 =
+// no activation), fp32 tensors: x (N, Cin, Di, Hi, Wi) with Wi % 4 == 0 and 16-byte aligned, y (N, Cout, (Di+1)/2, (Hi+1)/2,
+// (Wi+1)/2); xexps / wx from dca_conv3d_s2x2_prep_weight for THIS operand; y_cmax (may be null): per-channel slots [c][s],
+// s < dca_conv3d_s2x2_out_slots(...), that receive max |y|.
+extern "C" int dca_conv3d_s2x2_forward(const float* x, const int* xexps, const void* wx, float* y, const float* scale,
+                                       const float* shift, float slope, const float* res_post, unsigned* y_cmax, int N,
                                        int Cin, int Cout, int Di, int Hi, int Wi, hipStream_t stream) {
+  DCA_REQUIRE((scale == nullptr) == (shift == nullptr));
   DCA_REQUIRE(x && xexps && wx && y && N > 0 && Cin > 4 && Cin <= MAX_CIN && Cout > 0 && Di > 0 && Hi > 0 && Wi > 0);   // >= 2 chunks: the staging runs two chunks ahead
   DCA_REQUIRE(Wi % 4 == 0 && ((((uintptr_t)x) | ((uintptr_t)wx)) & 15) == 0);
   S2Args a;
   a.x = x; a.wx = (const unsigned short*)wx; a.y = y; a.res_post = res_post;
+  a.scale = scale; a.shift = shift; a.slope = slope; a.y_cmax = y_cmax;
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.NC4 = (Cin + 3) / 4;
   a.Di = Di; a.Hi = Hi; a.Wi = Wi;
   a.Do = (Di + 1) / 2; a.Ho = (Hi + 1) / 2; a.Wo = (Wi + 1) / 2;
@@ -459,8 +520,11 @@ extern "C" int dca_conv3d_s2x2_forward(const float* x, const int* xexps, const v
   int gx = ncu / cblks > 0 ? ncu / cblks : 1;
   if (gx > tiles) gx = (int)tiles;
   const int lds = LDS_BYTES + TAB_BYTES;
-  hipError_t e = hipFuncSetAttribute((const void*)conv3s2_f16x2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  const bool epi = scale != nullptr || slope != 1.f || y_cmax != nullptr;
+  DCA_REQUIRE(y_cmax == nullptr || gx <= DCA_AMAX_CSLOTS);
+  auto kern = epi ? conv3s2_f16x2_kernel<true> : conv3s2_f16x2_kernel<false>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(conv3s2_f16x2_kernel, dim3(gx, cblks), dim3(512), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3(gx, cblks), dim3(512), lds, stream, a);
   return dca_launch_status();
 }

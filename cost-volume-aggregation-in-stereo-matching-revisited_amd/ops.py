@@ -441,11 +441,12 @@ def _dx3_eligible(x, x2, ksize, stride, transposed, A, B):
 
 
 def _s2x2_eligible(x, x2, ksize, stride, transposed, A, B, scale, res_pre, slope):
-    """3x3x3 stride-2 convs on the f16x2 kernel of conv3d_s2_f16x2.hip: plain output (+ res_post), fine width divisible by 4,
-    16-byte aligned input, enough tiles to fill the chip (small volumes stay on the fp32 MFMA kernel)"""
+    """3x3x3 stride-2 convs on the f16x2 kernel of conv3d_s2_f16x2.hip: plain output or the inference epilogue (folded
+    BatchNorm, activation, res_post; no res_pre), fine width divisible by 4, 16-byte aligned input, enough tiles to fill the
+    chip (small volumes stay on the fp32 MFMA kernel)"""
     if not (CONV_X2 and CONV_X3 and CONV_S2_X2) or ksize != 3 or stride != 2 or transposed or x2 is not None:
         return False
-    if scale is not None or res_pre is not None or slope != 1.0 or A > 256 or A <= 4:
+    if res_pre is not None or A > 256 or A <= 4:
         return False
     N, _, D, H, W = x.shape
     Do, Ho, Wo = (D + 1) // 2, (H + 1) // 2, (W + 1) // 2
@@ -585,8 +586,12 @@ def _conv_sliced_impl(x, x2, w_src, A, B, K, src_ab, flip, ksize, stride, transp
                                              _ptr(xexps), _stream()), "dca_conv3d_s2x2_prep_weight")
         if slots is not None:
             x._dca_exps = (xexps, _ver(x))
-        _chk(lib.dca_conv3d_s2x2_forward(_ptr(x), _ptr(xexps), _ptr(wx), _ptr(y), _ptr(res_post), N, A, B, Di, Hi, Wi,
-                                         _stream()), "dca_conv3d_s2x2_forward")
+        nsl = lib.dca_conv3d_s2x2_out_slots(N, B, Di, Hi, Wi)
+        ycm = _cslots(B, x.device) if (emit_amax and nsl <= CSLOTS) else None
+        _chk(lib.dca_conv3d_s2x2_forward(_ptr(x), _ptr(xexps), _ptr(wx), _ptr(y), _ptr(scale), _ptr(shift), float(slope),
+                                         _ptr(res_post), _ptr(ycm), N, A, B, Di, Hi, Wi, _stream()), "dca_conv3d_s2x2_forward")
+        if ycm is not None:
+            _tag_cmax(y, ycm, nsl)
         return y, None
     if _dx3_eligible(x, x2, ksize, stride, transposed, A, B):
         def build_dx3():

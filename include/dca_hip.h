@@ -23,7 +23,7 @@ extern "C" {
 
 /* Bumped whenever an argument list below changes; the ctypes loader (_lib.py) refuses a library built from another
  * version of this header. */
-#define DCA_ABI_VERSION 18
+#define DCA_ABI_VERSION 19
 int dca_abi_version(void);
 
 /* storage types of the reduced-precision inference path (0 = fp32) */
@@ -238,14 +238,17 @@ int dca_conv3d_wgrad_s2_x2(const float* f, const int* f_exps, const float* c, co
 /* The STRIDE-2 3x3x3 convolution itself (padding 1) with the f16x2 arithmetic (conv3d_s2_f16x2.hip): `cost_agg.conv1` =
  * Conv3d(32, 64, 3, stride 2, padding 1) forward (models/augment/cva.py:16-17) and the backward-data of `cost_agg.conv3` =
  * ConvTranspose3d(64, 32, 3, stride 2, ...) (cva.py:21-29: the same operator over dy, weight read as [output][contraction]).
- * x (N,Cin,Di,Hi,Wi) fp32, Wi % 4 == 0, 16-byte aligned -> y (N,Cout,(Di+1)/2,(Hi+1)/2,(Wi+1)/2) = conv [+ res_post]; no
- * other epilogue (callers with a folded BatchNorm use dca_conv3d_forward).  Weights are packed per launch like
+ * x (N,Cin,Di,Hi,Wi) fp32, Wi % 4 == 0, 16-byte aligned -> y (N,Cout,(Di+1)/2,(Hi+1)/2,(Wi+1)/2) = act(conv * scale + shift) +
+ * res_post (all optional: the training launches use none; inference folds the BatchNorm; no res_pre); y_cmax (may be null) =
+ * per-channel slots [c][s], s < dca_conv3d_s2x2_out_slots(...), that receive max |y| for an f16x2 convolution reading y.  Weights are packed per launch like
  * dca_conv3d_x2_prep_weight (another fragment layout: K-steps of 4 channels x 4 taps, output-channel blocks of 64). */
 long dca_conv3d_s2x2_weight_bytes(int Cin, int Cout);
 int dca_conv3d_s2x2_prep_weight(const float* w, void* wx, int A, int B, int src_ab, int flip, const unsigned* x_slots,
                                 int nslots, int* xexps, hipStream_t stream);
-int dca_conv3d_s2x2_forward(const float* x, const int* xexps, const void* wx, float* y, const float* res_post, int N, int Cin,
-                            int Cout, int Di, int Hi, int Wi, hipStream_t stream);
+long dca_conv3d_s2x2_out_slots(int N, int Cout, int Di, int Hi, int Wi);
+int dca_conv3d_s2x2_forward(const float* x, const int* xexps, const void* wx, float* y, const float* scale, const float* shift,
+                            float slope, const float* res_post, unsigned* y_cmax, int N, int Cin, int Cout, int Di, int Hi, int Wi,
+                            hipStream_t stream);
 long dca_conv3d_wgrad_x2_workspace(int N, int Cx, int Cy, int D, int H, int W);
 int dca_conv3d_wgrad_x2(const void* x, int x_packed, const int* xexps, const void* dy, int dy_packed, const int* yexps,
                         float* part, float* dw, int N, int Cx, int Cy, int D, int H, int W, long s_cy, long s_cx,

@@ -1405,6 +1405,18 @@ def test_conv3d_s2_f16x2_matches_fp64(case, monkeypatch):
     res = seeded_tensor("s2x2.r", tuple(yr.shape))
     y2 = ops._conv_sliced(xg, None, wg, cin, cout, 27, 0, 0, 3, 2, False, res_post=gpu(res))
     assert torch.equal(y2, y + gpu(res))
+    # the inference epilogue: folded BatchNorm + leaky ReLU + res_post, and the per-channel maxima it emits for the next f16x2 conv
+    sc, sh = seeded_tensor("s2x2.sc", (cout,)) * 0.5 + 1.5, seeded_tensor("s2x2.sh", (cout,))
+    y3 = ops._conv_sliced(xg, None, wg, cin, cout, 27, 0, 0, 3, 2, False, scale=gpu(sc), shift=gpu(sh), slope=0.1,
+                          res_post=gpu(res), emit_amax=True)
+    ref3 = F.leaky_relu(yr * sc.double().view(1, -1, 1, 1, 1) + sh.double().view(1, -1, 1, 1, 1), 0.1) + res.double()
+    e3 = ((y3.cpu().double() - ref3).abs().amax((0, 2, 3, 4)) / (ref3.abs().amax((0, 2, 3, 4)) + scale)).max().item()
+    assert e3 <= 3e-6, e3
+    tag = getattr(y3, "_dca_cmax", None)
+    assert tag is not None
+    # (the maxima are those of the value BEFORE res_post is added?  no: of y as stored)
+    got = tag[0].view(torch.float32).view(cout, ops.CSLOTS)[:, :tag[1]].amax(1)
+    assert torch.equal(got, y3.abs().amax((0, 2, 3, 4))), (got, y3.abs().amax((0, 2, 3, 4)))
     # backward-data of ConvTranspose3d(cout_t = cin, ...) over dy = x: the same operator, weight (cin_t = cout, cout_t = cin)
     wt = seeded_tensor("s2x2.wt", (cout, cin, 3, 3, 3)) * 0.05 / spread.view(1, cin, 1, 1, 1)
     z = torch.zeros((N, cout) + tuple(yr.shape[2:]), dtype=torch.float64, requires_grad=True)
